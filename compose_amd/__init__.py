@@ -1,0 +1,572 @@
+"""compose_amd -- MI355X-native CEDR limiter hot path (QLT, CAAS, BFB tree all-reduce).
+
+This package is a thin ctypes binding of ``libcedr_hip.so`` (hand-written HIP
+kernels for gfx950 + C++ host classes), whose C ABI is declared in
+``include/cedr_hip.h``. The Python classes mirror the reference's plugin
+interface (cedr::CDR protocol, reference cedr/cedr_cdr.hpp:16-112): same method
+names, argument meaning and error behaviour (errors surface as ``CedrError``
+carrying the C++ ``std::logic_error`` text).
+
+There is NO CPU fallback: if the shared library is missing the import fails,
+and compute calls fail if no GPU is present.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+__all__ = ["CedrError", "ProblemType", "Parallel", "Tree", "QLT", "CAAS", "BfbTreeAllReducer",
+           "DeviceArray", "lib", "LIB_PATH", "build", "device_count"]
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcedr_hip.so")
+
+
+class CedrError(RuntimeError):
+    pass
+
+
+class ProblemType:
+    """reference cedr/cedr.hpp:29-39"""
+    conserve = 1
+    shapepreserve = 2
+    consistent = 4
+    nonnegative = 8
+
+
+def build():
+    """Compile libcedr_hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    import subprocess
+    subprocess.check_call(["make", "-s", "-C", os.path.join(_HERE, "csrc")])
+
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+_lp = C.POINTER(C.c_long)
+_vp = C.c_void_p
+
+USER_ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, _vp, _vp, _vp, C.c_int, C.c_int)
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, _vp, _vp, _vp, C.c_size_t, _vp)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, _vp, _vp, _vp, C.c_size_t, _vp)
+
+
+class _QltDeviceOp(C.Structure):
+    _fields_ = [("l2r_data", _vp), ("r2l_data", _vp), ("stride", C.c_int64),
+                ("trcr2prob", _vp), ("trcr2bl2r", _vp), ("trcr2br2l", _vp)]
+
+
+class _CaasDeviceOp(C.Structure):
+    _fields_ = [("d", _vp), ("nlclcells", C.c_int), ("nt", C.c_int), ("need_conserve", C.c_int)]
+
+
+_SIGS = {
+    # name: (restype, argtypes)
+    "cedr_last_error": (C.c_char_p, []),
+    "cedr_parallel_create_self": (_vp, []),
+    "cedr_rccl_get_unique_id": (C.c_int, [_vp]),
+    "cedr_parallel_create_rccl": (_vp, [_vp, C.c_int, C.c_int]),
+    "cedr_parallel_create_callbacks": (_vp, [C.c_int, C.c_int, ALLGATHER_FN, ALLREDUCE_FN, _vp]),
+    "cedr_parallel_rank": (C.c_int, [_vp]),
+    "cedr_parallel_size": (C.c_int, [_vp]),
+    "cedr_parallel_free": (None, [_vp]),
+    "cedr_tree_create": (_vp, [C.c_int, C.c_int, _ip, _ip, _ip, _lp]),
+    "cedr_tree_make_1d": (_vp, [C.c_int] * 4),
+    "cedr_tree_free": (None, [_vp]),
+    "cedr_tree_analyze": (_vp, [_vp, C.c_int, C.c_int]),
+    "cedr_ns_free": (None, [_vp]),
+    "cedr_ns_nslots": (C.c_int, [_vp]),
+    "cedr_ns_nnode": (C.c_int, [_vp]),
+    "cedr_ns_nlevels": (C.c_int, [_vp]),
+    "cedr_ns_level_size": (C.c_int, [_vp, C.c_int]),
+    "cedr_ns_level_nme": (C.c_int, [_vp, C.c_int]),
+    "cedr_ns_level_nkids": (C.c_int, [_vp, C.c_int]),
+    "cedr_ns_nodes": (None, [_vp, _ip]),
+    "cedr_ns_level_nodes": (None, [_vp, C.c_int, _ip]),
+    "cedr_ns_level_msgs": (None, [_vp, C.c_int, C.c_int, _ip]),
+    "cedr_ns_check_comm": (C.c_int, [_vp]),
+    "cedr_qlt_create": (_vp, [_vp, C.c_int, _vp, C.c_int]),
+    "cedr_qlt_free": (None, [_vp]),
+    "cedr_qlt_declare_tracer": (C.c_int, [_vp, C.c_int, C.c_int]),
+    "cedr_qlt_end_tracer_declarations": (C.c_int, [_vp]),
+    "cedr_qlt_get_buffers_sizes": (C.c_int, [_vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "cedr_qlt_set_buffers": (C.c_int, [_vp, _vp, _vp]),
+    "cedr_qlt_finish_setup": (C.c_int, [_vp]),
+    "cedr_qlt_get_problem_type": (C.c_int, [_vp, C.c_int]),
+    "cedr_qlt_get_num_tracers": (C.c_int, [_vp]),
+    "cedr_qlt_nlclcells": (C.c_int, [_vp]),
+    "cedr_qlt_get_owned_glblcells": (C.c_int, [_vp, _lp]),
+    "cedr_qlt_gci2lci": (C.c_int, [_vp, C.c_int]),
+    "cedr_qlt_run": (C.c_int, [_vp]),
+    "cedr_qlt_set_stream": (C.c_int, [_vp, _vp]),
+    "cedr_qlt_get_device_op": (C.c_int, [_vp, C.POINTER(_QltDeviceOp)]),
+    "cedr_qlt_set_rhom_bulk": (C.c_int, [_vp, _vp]),
+    "cedr_qlt_set_Qm_bulk": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    "cedr_qlt_get_Qm_bulk": (C.c_int, [_vp, _vp]),
+    "cedr_qlt_metadata": (C.c_int, [_vp] + [_ip] * 8),
+    "cedr_qlt_nodesets": (_vp, [_vp]),
+    "cedr_plan_create": (_vp, [_vp, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "cedr_plan_free": (None, [_vp]),
+    "cedr_qlt_plan": (_vp, [_vp]),
+    "cedr_plan_summary": (C.c_int, [_vp, C.POINTER(C.c_int64)]),
+    "cedr_plan_stage_sizes": (C.c_int, [_vp, C.c_int, C.c_int, _ip]),
+    "cedr_plan_stage": (C.c_int, [_vp, C.c_int, C.c_int, _ip, C.POINTER(C.c_uint16), _ip]),
+    "cedr_plan_exchange": (C.c_int, [_vp, _ip, _ip, _ip]),
+    "cedr_caas_create": (_vp, [_vp, C.c_int, USER_ALLREDUCE_FN, C.c_int, _vp]),
+    "cedr_caas_free": (None, [_vp]),
+    "cedr_caas_declare_tracer": (C.c_int, [_vp, C.c_int, C.c_int]),
+    "cedr_caas_end_tracer_declarations": (C.c_int, [_vp]),
+    "cedr_caas_get_buffers_sizes": (C.c_int, [_vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "cedr_caas_set_buffers": (C.c_int, [_vp, _vp, _vp]),
+    "cedr_caas_finish_setup": (C.c_int, [_vp]),
+    "cedr_caas_get_problem_type": (C.c_int, [_vp, C.c_int]),
+    "cedr_caas_get_num_tracers": (C.c_int, [_vp]),
+    "cedr_caas_run": (C.c_int, [_vp]),
+    "cedr_caas_set_stream": (C.c_int, [_vp, _vp]),
+    "cedr_caas_set_Qm_source": (C.c_int, [_vp, _vp]),
+    "cedr_caas_get_device_op": (C.c_int, [_vp, C.POINTER(_CaasDeviceOp)]),
+    "cedr_caas_get_recv": (C.c_int, [_vp, C.POINTER(_vp)]),
+    "cedr_bfb_create": (_vp, [_vp, _vp, C.c_int, C.c_int]),
+    "cedr_bfb_free": (None, [_vp]),
+    "cedr_bfb_nlocal": (C.c_int, [_vp]),
+    "cedr_bfb_allreduce": (C.c_int, [_vp, _vp, _vp, C.c_int]),
+    "cedr_device_count": (C.c_int, []),
+    "cedr_malloc": (_vp, [C.c_size_t]),
+    "cedr_free": (None, [_vp]),
+    "cedr_memcpy_h2d": (C.c_int, [_vp, _vp, C.c_size_t]),
+    "cedr_memcpy_d2h": (C.c_int, [_vp, _vp, C.c_size_t]),
+    "cedr_memcpy_d2d_async": (C.c_int, [_vp, _vp, C.c_size_t, _vp]),
+    "cedr_device_synchronize": (C.c_int, []),
+    # kernel level (layer K) entry points used directly by tests / bench
+    "cedr_hip_caas_nchunks": (C.c_int32, [C.c_int32]),
+    "cedr_hip_caas_reduce_local": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int, _vp, _vp, _vp, _vp]),
+    "cedr_hip_caas_sum_partials": (C.c_int, [C.c_int32, C.c_int32, _vp, _vp, _vp]),
+    "cedr_hip_caas_finish_local": (C.c_int, [C.c_int32, C.c_int32, _vp, _vp, _vp]),
+}
+
+_LIB = None
+
+
+def lib():
+    """Load libcedr_hip.so (once). Raises CedrError if it has not been built."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise CedrError("%s is missing: run compose_amd.build() (or `make -C compose_amd/csrc`). "
+                        "There is no CPU fallback." % LIB_PATH)
+    L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    _LIB = L
+    return L
+
+
+def _err():
+    return lib().cedr_last_error().decode(errors="replace")
+
+
+def _chk(rc, what=""):
+    if rc != 0:
+        msg = _err() if rc == -1 else "HIP error %d" % rc
+        raise CedrError("%s: %s" % (what, msg) if what else msg)
+
+
+def _handle(h, what):
+    if not h:
+        raise CedrError("%s: %s" % (what, _err()))
+    return h
+
+
+def device_count():
+    return lib().cedr_device_count()
+
+
+def _ptr(x):
+    """Device pointer of a DeviceArray, torch tensor, int or None."""
+    if x is None:
+        return None
+    if isinstance(x, DeviceArray):
+        return x.ptr
+    if isinstance(x, int):
+        return x
+    if hasattr(x, "data_ptr"):
+        return x.data_ptr()
+    raise TypeError("expected a device array, got %r" % type(x))
+
+
+class DeviceArray:
+    """A hipMalloc'ed array of doubles (or ints) with numpy upload/download."""
+
+    def __init__(self, n, dtype=np.float64):
+        self.dtype = np.dtype(dtype)
+        self.n = int(n)
+        self.ptr = _handle(lib().cedr_malloc(max(1, self.n) * self.dtype.itemsize), "cedr_malloc")
+
+    @staticmethod
+    def from_numpy(a):
+        a = np.ascontiguousarray(a)
+        d = DeviceArray(a.size, a.dtype)
+        d.upload(a)
+        return d
+
+    def upload(self, a):
+        a = np.ascontiguousarray(a, self.dtype)
+        assert a.size <= self.n
+        _chk(lib().cedr_memcpy_h2d(self.ptr, a.ctypes.data, a.size * self.dtype.itemsize), "h2d")
+
+    def numpy(self, shape=None):
+        out = np.empty(self.n, self.dtype)
+        _chk(lib().cedr_memcpy_d2h(out.ctypes.data, self.ptr, self.n * self.dtype.itemsize), "d2h")
+        return out if shape is None else out.reshape(shape)
+
+    def offset(self, nelem):
+        return self.ptr + int(nelem) * self.dtype.itemsize
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                lib().cedr_free(self.ptr)
+        except Exception:
+            pass
+
+
+class Parallel:
+    """cedr::mpi::Parallel (reference cedr/cedr_mpi.hpp:17-27)."""
+
+    def __init__(self, handle, keep=None):
+        self.h = _handle(handle, "Parallel")
+        self._keep = keep
+
+    @staticmethod
+    def self_():
+        return Parallel(lib().cedr_parallel_create_self())
+
+    @staticmethod
+    def rccl(unique_id, rank, size):
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        return Parallel(lib().cedr_parallel_create_rccl(buf, rank, size))
+
+    @staticmethod
+    def rccl_unique_id():
+        buf = C.create_string_buffer(128)
+        rc = lib().cedr_rccl_get_unique_id(buf)
+        if rc != 0:
+            raise CedrError("ncclGetUniqueId failed (%d)" % rc)
+        return buf.raw
+
+    @staticmethod
+    def callbacks(rank, size, allgather, allreduce_sum):
+        """allgather(send_ptr, recv_ptr, count, stream) / allreduce_sum(...) -> int, on device pointers."""
+        ag = ALLGATHER_FN(lambda user, s, r, n, st: int(allgather(s, r, n, st) or 0))
+        ar = ALLREDUCE_FN(lambda user, s, r, n, st: int(allreduce_sum(s, r, n, st) or 0))
+        return Parallel(lib().cedr_parallel_create_callbacks(rank, size, ag, ar, None), keep=(ag, ar))
+
+    def rank(self):
+        return lib().cedr_parallel_rank(self.h)
+
+    def size(self):
+        return lib().cedr_parallel_size(self.h)
+
+    def root(self):
+        return 0
+
+    def amroot(self):
+        return self.rank() == 0
+
+    def __del__(self):
+        try:
+            lib().cedr_parallel_free(self.h)
+        except Exception:
+            pass
+
+
+class Tree:
+    """The caller's tree (reference cedr/cedr_tree_caller.hpp:12-30), in array form."""
+
+    def __init__(self, handle):
+        self.h = _handle(handle, "Tree")
+
+    @staticmethod
+    def make_1d(ncells, nranks=1, pseudorandom=False, imbalanced=False):
+        """tree::oned::make_tree over Mesh(ncells) (reference cedr/cedr_tree.cpp:366-420)."""
+        return Tree(lib().cedr_tree_make_1d(ncells, nranks, int(pseudorandom), int(imbalanced)))
+
+    @staticmethod
+    def from_arrays(root, kid0, kid1, rank, cellidx):
+        kid0 = np.ascontiguousarray(kid0, np.int32)
+        kid1 = np.ascontiguousarray(kid1, np.int32)
+        rank = np.ascontiguousarray(rank, np.int32)
+        cellidx = np.ascontiguousarray(cellidx, np.int64)
+        return Tree(lib().cedr_tree_create(len(kid0), int(root), kid0.ctypes.data_as(_ip),
+                                           kid1.ctypes.data_as(_ip), rank.ctypes.data_as(_ip),
+                                           cellidx.ctypes.data_as(_lp)))
+
+    def analyze(self, ncells, rank):
+        """tree::analyze -> dict of integer arrays (NodeSets, reference cedr/cedr_tree.hpp:16-97)."""
+        h = _handle(lib().cedr_tree_analyze(self.h, ncells, rank), "analyze")
+        try:
+            return dump_nodesets(h)
+        finally:
+            lib().cedr_ns_free(h)
+
+    def plan(self, ncells, rank, nranks, max_tile_leaves=0):
+        h = _handle(lib().cedr_plan_create(self.h, ncells, rank, nranks, max_tile_leaves), "plan")
+        try:
+            return dump_plan(h, nranks)
+        finally:
+            lib().cedr_plan_free(h)
+
+    def __del__(self):
+        try:
+            lib().cedr_tree_free(self.h)
+        except Exception:
+            pass
+
+
+def dump_nodesets(h):
+    L = lib()
+    nn = L.cedr_ns_nnode(h)
+    nodes = np.zeros((nn, 7), np.int32)
+    L.cedr_ns_nodes(h, nodes.ctypes.data_as(_ip))
+    levels = []
+    for il in range(L.cedr_ns_nlevels(h)):
+        ln = np.zeros(L.cedr_ns_level_size(h, il), np.int32)
+        L.cedr_ns_level_nodes(h, il, ln.ctypes.data_as(_ip))
+        me = np.zeros((L.cedr_ns_level_nme(h, il), 3), np.int32)
+        kids = np.zeros((L.cedr_ns_level_nkids(h, il), 3), np.int32)
+        if len(me):
+            L.cedr_ns_level_msgs(h, il, 0, me.ctypes.data_as(_ip))
+        if len(kids):
+            L.cedr_ns_level_msgs(h, il, 1, kids.ctypes.data_as(_ip))
+        levels.append(dict(nodes=ln, me=me, kids=kids))
+    return dict(nslots=L.cedr_ns_nslots(h), nodes=nodes, levels=levels,
+                check_comm=L.cedr_ns_check_comm(h))
+
+
+def dump_plan(h, nranks=1):
+    L = lib()
+    s = (C.c_int64 * 8)()
+    L.cedr_plan_summary(h, s)
+    out = dict(nlcl=s[0], nslots=s[1], root_slot=s[4], nb_max=s[5], nmyroots=s[6], stride=s[7],
+               local=[], top=[])
+    for top, key, cnt in ((0, "local", s[2]), (1, "top", s[3])):
+        for i in range(cnt):
+            sz = (C.c_int * 4)()
+            _chk(L.cedr_plan_stage_sizes(h, top, i, sz))
+            tiles = np.zeros((sz[0], 8), np.int32)
+            kids = np.zeros((sz[2], 2), np.uint16)
+            lvlptr = np.zeros(sz[3], np.int32)
+            _chk(L.cedr_plan_stage(h, top, i, tiles.ctypes.data_as(_ip),
+                                   kids.ctypes.data_as(C.POINTER(C.c_uint16)), lvlptr.ctypes.data_as(_ip)))
+            out[key].append(dict(tiles=tiles, kids=kids, lvlptr=lvlptr, max_nodes=sz[1]))
+    out["my_root_slots"], out["my_top_slots"], out["gather_slots"] = plan_exchange(h, nranks)
+    return out
+
+
+def plan_exchange(h, nranks):
+    """(my_root_slots, my_top_slots, gather_slots[nranks][nb_max]) of a plan handle."""
+    L = lib()
+    s = (C.c_int64 * 8)()
+    L.cedr_plan_summary(h, s)
+    nm, nb = int(s[6]), int(s[5])
+    mr = np.zeros(nm, np.int32)
+    mt = np.zeros(nm if s[3] else 0, np.int32)
+    gs = np.zeros(nranks * nb if s[3] else 0, np.int32)
+    # arrays with zero length still need valid pointers
+    pad = np.zeros(1, np.int32)
+    L.cedr_plan_exchange(h, (mr if nm else pad).ctypes.data_as(_ip),
+                         (mt if len(mt) else pad).ctypes.data_as(_ip),
+                         (gs if len(gs) else pad).ctypes.data_as(_ip))
+    return mr, mt, gs.reshape(nranks, nb) if len(gs) else gs
+
+
+class _CDR:
+    """Shared CDR protocol (reference cedr/cedr_cdr.hpp:38-107)."""
+    _pfx = ""
+
+    def _f(self, name):
+        return getattr(lib(), self._pfx + name)
+
+    def declare_tracer(self, problem_type, rhomidx=0):
+        _chk(self._f("declare_tracer")(self.h, int(problem_type), int(rhomidx)), "declare_tracer")
+
+    def end_tracer_declarations(self):
+        _chk(self._f("end_tracer_declarations")(self.h), "end_tracer_declarations")
+
+    def get_buffers_sizes(self):
+        b1, b2 = C.c_size_t(), C.c_size_t()
+        _chk(self._f("get_buffers_sizes")(self.h, C.byref(b1), C.byref(b2)), "get_buffers_sizes")
+        return b1.value, b2.value
+
+    def set_buffers(self, buf1, buf2):
+        self._bufs = (buf1, buf2)
+        _chk(self._f("set_buffers")(self.h, _ptr(buf1), _ptr(buf2)), "set_buffers")
+
+    def finish_setup(self):
+        _chk(self._f("finish_setup")(self.h), "finish_setup")
+
+    def get_problem_type(self, tracer_idx):
+        rc = self._f("get_problem_type")(self.h, int(tracer_idx))
+        if rc < 0:
+            raise CedrError(_err())
+        return rc
+
+    def get_num_tracers(self):
+        return self._f("get_num_tracers")(self.h)
+
+    def run(self):
+        _chk(self._f("run")(self.h), "run")
+
+    def set_stream(self, stream):
+        _chk(self._f("set_stream")(self.h, stream), "set_stream")
+
+
+class QLT(_CDR):
+    """cedr::qlt::QLT (reference cedr/cedr_qlt.hpp:129-197)."""
+    _pfx = "cedr_qlt_"
+
+    def __init__(self, parallel, ncells, tree, prefer_mass_con_to_bounds=False):
+        self.p, self.tree = parallel, tree
+        self.h = _handle(lib().cedr_qlt_create(parallel.h, int(ncells), tree.h,
+                                               int(prefer_mass_con_to_bounds)), "QLT")
+
+    def nlclcells(self):
+        return lib().cedr_qlt_nlclcells(self.h)
+
+    def get_owned_glblcells(self):
+        g = np.zeros(self.nlclcells(), np.int64)
+        _chk(lib().cedr_qlt_get_owned_glblcells(self.h, g.ctypes.data_as(_lp)))
+        return g
+
+    def gci2lci(self, gci):
+        rc = lib().cedr_qlt_gci2lci(self.h, int(gci))
+        if rc < 0:
+            raise CedrError(_err())
+        return rc
+
+    def get_device_op(self):
+        op = _QltDeviceOp()
+        lib().cedr_qlt_get_device_op(self.h, C.byref(op))
+        return op
+
+    def set_rhom(self, rhom):
+        """Bulk DeviceOp::set_rhom over all local cells; rhom is a device array [cell]."""
+        _chk(lib().cedr_qlt_set_rhom_bulk(self.h, _ptr(rhom)), "set_rhom")
+
+    def set_Qm(self, Qm, Qm_min, Qm_max, Qm_prev):
+        """Bulk DeviceOp::set_Qm; device arrays [tracer][cell] in caller tracer order."""
+        _chk(lib().cedr_qlt_set_Qm_bulk(self.h, _ptr(Qm), _ptr(Qm_min), _ptr(Qm_max), _ptr(Qm_prev)),
+             "set_Qm")
+
+    def get_Qm(self, out):
+        _chk(lib().cedr_qlt_get_Qm_bulk(self.h, _ptr(out)), "get_Qm")
+
+    def metadata(self):
+        nt = self.get_num_tracers()
+        a = [np.zeros(nt, np.int32) for _ in range(5)] + [np.zeros(7, np.int32) for _ in range(3)]
+        lib().cedr_qlt_metadata(self.h, *[x.ctypes.data_as(_ip) for x in a])
+        keys = ["trcr2prob", "bidx2trcr", "trcr2bidx", "trcr2bl2r", "trcr2br2l",
+                "prob2trcrptr", "prob2bl2r", "prob2br2l"]
+        return dict(zip(keys, a))
+
+    def nodesets(self):
+        return dump_nodesets(lib().cedr_qlt_nodesets(self.h))
+
+    def plan(self):
+        return dump_plan(lib().cedr_qlt_plan(self.h), self.p.size())
+
+    def __del__(self):
+        try:
+            lib().cedr_qlt_free(self.h)
+        except Exception:
+            pass
+
+
+class CAAS(_CDR):
+    """cedr::caas::CAAS (reference cedr/cedr_caas.hpp:51-96).
+
+    user_reducer(send_ptr, recv_ptr, nlocal, nfld) -> int mirrors
+    CAAS::UserAllReducer::operator() (cedr_caas.hpp:31-40) on device pointers.
+    """
+    _pfx = "cedr_caas_"
+
+    def __init__(self, parallel, nlclcells, user_reducer=None, n_accum_in_place=1):
+        self.p = parallel
+        if user_reducer is not None:
+            self._cb = USER_ALLREDUCE_FN(lambda user, s, r, nl, nf: int(user_reducer(s, r, nl, nf) or 0))
+        else:
+            self._cb = C.cast(None, USER_ALLREDUCE_FN)
+        self.h = _handle(lib().cedr_caas_create(parallel.h, int(nlclcells), self._cb,
+                                                int(n_accum_in_place), None), "CAAS")
+        self.n = int(nlclcells)
+
+    def get_device_op(self):
+        op = _CaasDeviceOp()
+        lib().cedr_caas_get_device_op(self.h, C.byref(op))
+        return op
+
+    def set_Qm_source(self, qm_src):
+        self._src = qm_src
+        _chk(lib().cedr_caas_set_Qm_source(self.h, _ptr(qm_src)))
+
+    def _copy(self, row0, src, nrows):
+        op = self.get_device_op()
+        nbytes = 8 * self.n * nrows
+        _chk(lib().cedr_memcpy_d2d_async(op.d + 8 * self.n * row0, _ptr(src), nbytes, None), "copy")
+
+    def set_rhom(self, rhom):
+        """Bulk DeviceOp::set_rhom (cedr_caas_inl.hpp:14-19)."""
+        self._copy(0, rhom, 1)
+
+    def set_Qm(self, Qm, Qm_min, Qm_max, Qm_prev=None):
+        """Bulk DeviceOp::set_Qm (cedr_caas_inl.hpp:22-34): the layouts coincide, so plain copies."""
+        op = self.get_device_op()
+        nt = op.nt
+        self._copy(1, Qm, nt)
+        self._copy(1 + nt, Qm_min, nt)
+        self._copy(1 + 2 * nt, Qm_max, nt)
+        if op.need_conserve:
+            if Qm_prev is None:
+                raise CedrError("Qm_prev was not provided to set_Qm.")
+            self._copy(1 + 3 * nt, Qm_prev, nt)
+
+    def get_Qm(self, out):
+        op = self.get_device_op()
+        _chk(lib().cedr_memcpy_d2d_async(_ptr(out), op.d + 8 * self.n, 8 * self.n * op.nt, None))
+
+    def recv_ptr(self):
+        p = _vp()
+        lib().cedr_caas_get_recv(self.h, C.byref(p))
+        return p.value
+
+    def __del__(self):
+        try:
+            lib().cedr_caas_free(self.h)
+        except Exception:
+            pass
+
+
+class BfbTreeAllReducer:
+    """cedr::BfbTreeAllReducer (reference cedr/cedr_bfb_tree_allreduce.hpp:14-57)."""
+
+    def __init__(self, parallel, tree, nleaf, nfield):
+        self.p, self.tree, self.nfield = parallel, tree, nfield
+        self.h = _handle(lib().cedr_bfb_create(parallel.h, tree.h, int(nleaf), int(nfield)), "Bfb")
+
+    def nlocal(self):
+        return lib().cedr_bfb_nlocal(self.h)
+
+    def allreduce(self, send, recv, transpose=False):
+        _chk(lib().cedr_bfb_allreduce(self.h, _ptr(send), _ptr(recv), int(transpose)), "allreduce")
+
+    def __del__(self):
+        try:
+            lib().cedr_bfb_free(self.h)
+        except Exception:
+            pass
+
+
+def synchronize():
+    _chk(lib().cedr_device_synchronize(), "synchronize")

@@ -1,0 +1,81 @@
+#include "cedr_bfb_tree_allreduce.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include "../../include/cedr_hip.h"
+#include "cedr_device.hpp"
+#include "cedr_engine.hpp"
+#include "cedr_util.hpp"
+
+namespace cedr {
+
+#define cedr_k_check(call) do {                                         \
+    const int _e_ = (call);                                             \
+    cedr_throw_if(_e_ != 0, "kernel launch failed with HIP error " << _e_ << " in " #call); \
+  } while (0)
+
+struct BfbTreeAllReducerHip::Impl {
+  hipStream_t stream = nullptr;
+  dev::Buffer<Real> bd;          // [nfield][stride]
+  dev::Buffer<int32_t> leaf_slots, root_slot;
+  dev::Buffer<uint8_t> op;       // all sums
+};
+
+void BfbTreeAllReducerHip::init (const mpi::Parallel::Ptr& p, const tree::FlatTree& tree,
+                                 const Int nleaf, const Int nfield) {
+  p_ = p;
+  ns_ = tree::analyze(p->rank(), nleaf, tree);
+  cedr_throw_if(ns_->levels.empty() || ns_->levels[0].nodes.empty(),
+                "BfbTreeAllReducer does not support 0 leaves on a rank.");
+  nlocal_ = static_cast<Int>(ns_->levels[0].nodes.size());
+  nfield_ = nfield;
+  eng_.reset(new engine::TreeEngine(p, tree, *ns_, plan::Options()));
+  m_.reset(new Impl());
+}
+
+BfbTreeAllReducerHip::BfbTreeAllReducerHip (const mpi::Parallel::Ptr& p,
+                                            const tree::Node::Ptr& tree, const Int nleaf,
+                                            const Int nfield) {
+  init(p, tree::flatten(tree), nleaf, nfield);
+}
+
+BfbTreeAllReducerHip::BfbTreeAllReducerHip (const mpi::Parallel::Ptr& p,
+                                            const tree::FlatTree& tree, const Int nleaf,
+                                            const Int nfield) {
+  init(p, tree, nleaf, nfield);
+}
+
+BfbTreeAllReducerHip::~BfbTreeAllReducerHip () {}
+
+void BfbTreeAllReducerHip::get_host_buffers_sizes (size_t& buf1, size_t& buf2) { buf1 = buf2 = 0; }
+void BfbTreeAllReducerHip::set_host_buffers (Real*, Real*) {}
+void BfbTreeAllReducerHip::set_stream (hipStream_t stream) { m_->stream = stream; }
+
+void BfbTreeAllReducerHip::finish_setup () {
+  if (m_->bd.size()) return;
+  m_->bd.alloc_zero(static_cast<size_t>(nfield_)*eng_->stride());
+  // send's i-th leaf is levels[0].nodes[i] (cedr_bfb_tree_allreduce.cpp:91-102).
+  std::vector<int32_t> ls(nlocal_);
+  for (Int i = 0; i < nlocal_; ++i) ls[i] = ns_->node_h(ns_->levels[0].nodes[i])->offset;
+  m_->leaf_slots.upload(ls);
+  m_->root_slot.upload(std::vector<int32_t>(1, eng_->get_plan().root_slot));
+  m_->op.upload(std::vector<uint8_t>(nfield_, 0));
+}
+
+void BfbTreeAllReducerHip::allreduce (const Real* send, Real* recv, const bool transpose) const {
+  if ( ! m_->bd.size()) const_cast<BfbTreeAllReducerHip*>(this)->finish_setup();
+  hipStream_t s = m_->stream;
+  Real* const bd = m_->bd.data();
+  const int64_t S = eng_->stride();
+  if (transpose)
+    cedr_k_check(cedr_hip_scatter_slots_fm(bd, S, nfield_, m_->leaf_slots.data(), nlocal_, send, s));
+  else
+    cedr_k_check(cedr_hip_scatter_slots(bd, S, nfield_, m_->leaf_slots.data(), nlocal_, send, s));
+  // Every node is 0 + kid0 + kid1, as in cedr_bfb_tree_allreduce.cpp:117-123.
+  eng_->up(nfield_, m_->op.data(), bd, true, s);
+  // The root's record is the result on every rank (:68-76 read it back from
+  // the first leaf after the root->leaves copies; the value is the same).
+  cedr_k_check(cedr_hip_gather_slots(bd, S, nfield_, m_->root_slot.data(), 1, recv, s));
+}
+
+}  // namespace cedr

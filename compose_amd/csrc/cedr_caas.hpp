@@ -1,0 +1,109 @@
+// CAAS: ClipAndAssuredSum. Public surface follows reference
+// cedr/cedr_caas.hpp:16-121; the kernels are in cedr_kernels.hip.
+#ifndef COMPOSE_AMD_CEDR_CAAS_HPP
+#define COMPOSE_AMD_CEDR_CAAS_HPP
+
+#include <memory>
+#include <vector>
+
+#include "cedr_cdr.hpp"
+
+typedef struct ihipStream_t* hipStream_t;
+
+// The reference's UserAllReducer takes an MPI_Op. Builds without MPI get a
+// stand-in type so caller code keeps compiling; only MPI_SUM is ever passed.
+#if ! defined(MPI_VERSION) && ! defined(CEDR_NO_MPI_OP_STANDIN)
+typedef int MPI_Op;
+# ifndef MPI_SUM
+#  define MPI_SUM 1
+# endif
+#endif
+
+namespace cedr {
+namespace caas {
+
+class CAASHip : public CDR {
+public:
+  typedef std::shared_ptr<CAASHip> Ptr;
+
+  // reference cedr_caas.hpp:27-49. sendbuf/rcvbuf are DEVICE pointers, as in
+  // the reference's GPU build.
+  struct UserAllReducer {
+    typedef std::shared_ptr<const UserAllReducer> Ptr;
+    virtual ~UserAllReducer () {}
+    virtual int operator()(const mpi::Parallel& p, Real* sendbuf, Real* rcvbuf,
+                           int nlocal, int nfld, MPI_Op op) const = 0;
+    virtual int n_accum_in_place () const { return 1; }
+  };
+
+  CAASHip(const mpi::Parallel::Ptr& p, const Int nlclcells,
+          const UserAllReducer::Ptr& r = nullptr);
+  ~CAASHip();
+
+  void declare_tracer(int problem_type, const Int& rhomidx) override;
+  void end_tracer_declarations() override;
+  void get_buffers_sizes(size_t& buf1, size_t& buf2) override;
+  void set_buffers(Real* buf1, Real* buf2) override;
+  void finish_setup() override;
+  int get_problem_type(const Int& tracer_idx) const override;
+  Int get_num_tracers() const override;
+
+  // reference cedr_caas_inl.hpp:14-42: d is SoA, d[(1 + a*nt + tracer)*n + cell].
+  struct DeviceOp : public CDR::DeviceOp {
+    CEDR_DEVICE_INLINE void set_rhom (const Int& lclcellidx, const Int&, const Real& rhom) const {
+      d_[lclcellidx] = rhom;
+    }
+    CEDR_DEVICE_INLINE void set_Qm (const Int& lclcellidx, const Int& tracer_idx, const Real& Qm,
+                                    const Real& Qm_min, const Real& Qm_max,
+                                    const Real Qm_prev = std::numeric_limits<Real>::infinity()) const {
+      const int64_t n = nlclcells_;
+      d_[(1 +         tracer_idx)*n + lclcellidx] = Qm;
+      d_[(1 +   nt_ + tracer_idx)*n + lclcellidx] = Qm_min;
+      d_[(1 + 2*nt_ + tracer_idx)*n + lclcellidx] = Qm_max;
+      if (need_conserve_) d_[(1 + 3*nt_ + tracer_idx)*n + lclcellidx] = Qm_prev;
+    }
+    CEDR_DEVICE_INLINE Real get_Qm (const Int& lclcellidx, const Int& tracer_idx) const {
+      return d_[(1 + tracer_idx)*static_cast<int64_t>(nlclcells_) + lclcellidx];
+    }
+    Int nlclcells_, nrhomidxs_, nt_;
+    bool need_conserve_;
+    Real* d_;
+  };
+  const DeviceOp& get_device_op();
+
+  void run() override;
+
+  // ---- additions of this build ----
+  void set_stream(hipStream_t stream);
+  // If set, reduce_locally reads the unclipped Qm from this device array
+  // ([tracer][cell]) instead of from the data buffer; the clipped and final
+  // values still land in the data buffer. Same arithmetic and traffic as the
+  // in-place form; lets a caller keep its own Qm untouched.
+  void set_Qm_source(const Real* qm_src);
+  const Real* send_data () const;
+  const Real* recv_data () const;
+
+  // Exposed for tests: the three steps of run(), reference cedr_caas.cpp:129-253.
+  void reduce_locally();
+  void reduce_globally();
+  void finish_locally();
+
+private:
+  struct Impl;
+  mpi::Parallel::Ptr p_;
+  UserAllReducer::Ptr user_reducer_;
+  std::unique_ptr<std::vector<int> > tracer_decls_;
+  std::vector<Int> probs_h_;
+  bool finished_setup_;
+  std::unique_ptr<Impl> m_;
+  DeviceOp o;
+
+  void get_buffers_sizes(size_t& buf1, size_t& buf2, size_t& buf3);
+};
+
+template <typename ExeSpace = cedr::Hip> using CAAS = CAASHip;
+
+}  // namespace caas
+}  // namespace cedr
+
+#endif

@@ -1,0 +1,367 @@
+// Object-level C ABI (layer O of include/cedr_hip.h) over the C++ host classes.
+// Nothing throws across this boundary: exceptions become -1 / NULL and a
+// message retrievable with cedr_last_error().
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <exception>
+#include <map>
+#include <string>
+
+#include "../../include/cedr_hip.h"
+#include "cedr_bfb_tree_allreduce.hpp"
+#include "cedr_caas.hpp"
+#include "cedr_engine.hpp"
+#include "cedr_qlt.hpp"
+#include "cedr_tree.hpp"
+#include "cedr_util.hpp"
+
+using namespace cedr;
+
+namespace {
+thread_local std::string g_err;
+
+struct ParallelBox { mpi::Parallel::Ptr p; };
+struct TreeBox { tree::FlatTree t; };
+struct NsBox { tree::NodeSets::ConstPtr owned; const tree::NodeSets* ns; };
+struct PlanBox { plan::Plan owned; const plan::Plan* p; int64_t stride; };
+struct QltBox { std::unique_ptr<qlt::QLTHip> q; NsBox ns; PlanBox plan; };
+struct BfbBox { std::unique_ptr<BfbTreeAllReducerHip> b; };
+
+struct CbReducer : public caas::CAASHip::UserAllReducer {
+  cedr_user_allreduce_fn fn; int nacc; void* user;
+  CbReducer (cedr_user_allreduce_fn f, int n, void* u) : fn(f), nacc(n), user(u) {}
+  int operator() (const mpi::Parallel&, Real* s, Real* r, int nlocal, int nfld, MPI_Op) const override {
+    return fn(user, s, r, nlocal, nfld);
+  }
+  int n_accum_in_place () const override { return nacc; }
+};
+struct CaasBox { std::unique_ptr<caas::CAASHip> c; };
+}  // namespace
+
+#define CEDR_TRY try {
+#define CEDR_CATCH(ret) } catch (const std::exception& e) { g_err = e.what(); return ret; } \
+  catch (...) { g_err = "unknown exception"; return ret; }
+
+extern "C" {
+
+const char* cedr_last_error (void) { return g_err.c_str(); }
+
+// ------------------------------------------------------------------ Parallel
+void* cedr_parallel_create_self (void) {
+  CEDR_TRY return new ParallelBox{mpi::make_parallel()}; CEDR_CATCH(nullptr)
+}
+int cedr_rccl_get_unique_id (void* id) { return mpi::rccl_get_unique_id(id); }
+void* cedr_parallel_create_rccl (const void* id, int rank, int size) {
+  CEDR_TRY return new ParallelBox{mpi::make_parallel_rccl(id, rank, size)}; CEDR_CATCH(nullptr)
+}
+void* cedr_parallel_create_callbacks (int rank, int size, cedr_allgather_fn ag,
+                                      cedr_allreduce_sum_fn ar, void* user) {
+  CEDR_TRY
+  return new ParallelBox{mpi::make_parallel_callbacks(rank, size, ag, ar, user)};
+  CEDR_CATCH(nullptr)
+}
+int cedr_parallel_rank (void* p) { return static_cast<ParallelBox*>(p)->p->rank(); }
+int cedr_parallel_size (void* p) { return static_cast<ParallelBox*>(p)->p->size(); }
+void cedr_parallel_free (void* p) { delete static_cast<ParallelBox*>(p); }
+
+// ---------------------------------------------------------------------- trees
+void* cedr_tree_create (int nnodes, int root, const int* kid0, const int* kid1, const int* rank,
+                        const long* cellidx) {
+  CEDR_TRY
+  cedr_throw_if(nnodes < 1 || root < 0 || root >= nnodes, "bad tree size or root");
+  TreeBox* tb = new TreeBox();
+  tree::FlatTree& t = tb->t;
+  struct Item { int src, fparent, which; };
+  std::vector<Item> stack(1, Item{root, -1, 0});
+  int visited = 0;
+  while ( ! stack.empty()) {
+    const Item it = stack.back();
+    stack.pop_back();
+    cedr_throw_if(++visited > nnodes, "tree arrays contain a cycle");
+    const Int me = t.add(it.fparent);
+    if (it.fparent >= 0) (it.which == 0 ? t.kid0 : t.kid1)[it.fparent] = me;
+    t.rank[me] = rank[it.src];
+    t.cellidx[me] = cellidx[it.src];
+    const int k0 = kid0[it.src], k1 = kid1[it.src];
+    cedr_throw_if((k0 < 0) != (k1 < 0), "a node has exactly one kid; only binary trees are supported");
+    if (k0 >= 0) {
+      cedr_throw_if(k0 >= nnodes || k1 >= nnodes, "kid index out of range");
+      t.nkids[me] = 2;
+      stack.push_back(Item{k1, me, 1});
+      stack.push_back(Item{k0, me, 0});
+    }
+  }
+  return tb;
+  CEDR_CATCH(nullptr)
+}
+
+void* cedr_tree_make_1d (int ncells, int nranks, int pseudorandom, int imbalanced) {
+  CEDR_TRY
+  typedef tree::oned::Mesh Mesh;
+  const Mesh m(ncells, nranks, pseudorandom ? Mesh::ParallelDecomp::pseudorandom
+                                            : Mesh::ParallelDecomp::contiguous);
+  return new TreeBox{tree::oned::make_flat_tree(m, imbalanced != 0)};
+  CEDR_CATCH(nullptr)
+}
+void cedr_tree_free (void* t) { delete static_cast<TreeBox*>(t); }
+
+// ------------------------------------------------------------------- NodeSets
+void* cedr_tree_analyze (void* tree, int ncells, int my_rank) {
+  CEDR_TRY
+  NsBox* b = new NsBox();
+  b->owned = tree::analyze(my_rank, ncells, static_cast<TreeBox*>(tree)->t);
+  b->ns = b->owned.get();
+  return b;
+  CEDR_CATCH(nullptr)
+}
+void cedr_ns_free (void* ns) { delete static_cast<NsBox*>(ns); }
+#define NS(h) (*static_cast<NsBox*>(h)->ns)
+int cedr_ns_nslots (void* h) { return NS(h).nslots; }
+int cedr_ns_nnode (void* h) { return NS(h).nnode(); }
+int cedr_ns_nlevels (void* h) { return static_cast<int>(NS(h).levels.size()); }
+int cedr_ns_level_size (void* h, int il) { return static_cast<int>(NS(h).levels[il].nodes.size()); }
+int cedr_ns_level_nme (void* h, int il) { return static_cast<int>(NS(h).levels[il].me.size()); }
+int cedr_ns_level_nkids (void* h, int il) { return static_cast<int>(NS(h).levels[il].kids.size()); }
+void cedr_ns_nodes (void* h, int* out) {
+  const tree::NodeSets& ns = NS(h);
+  for (Int i = 0; i < ns.nnode(); ++i) {
+    const auto n = ns.node_h(i);
+    int* o = out + 7*i;
+    o[0] = n->rank; o[1] = n->id; o[2] = n->parent; o[3] = n->nkids;
+    o[4] = n->kids[0]; o[5] = n->kids[1]; o[6] = n->offset;
+  }
+}
+void cedr_ns_level_nodes (void* h, int il, int* out) {
+  const auto& v = NS(h).levels[il].nodes;
+  std::copy(v.begin(), v.end(), out);
+}
+void cedr_ns_level_msgs (void* h, int il, int which, int* out) {
+  const auto& lvl = NS(h).levels[il];
+  const auto& v = which == 0 ? lvl.me : lvl.kids;
+  for (size_t i = 0; i < v.size(); ++i) {
+    out[3*i] = v[i].rank; out[3*i+1] = v[i].offset; out[3*i+2] = v[i].size;
+  }
+}
+int cedr_ns_check_comm (void* h) { return tree::check_comm(NS(h)); }
+
+// ------------------------------------------------------------------------ QLT
+#define Q(h) (*static_cast<QltBox*>(h)->q)
+void* cedr_qlt_create (void* parallel, int ncells, void* tree, int prefer) {
+  CEDR_TRY
+  CDR::Options o;
+  o.prefer_numerical_mass_conservation_to_numerical_bounds = prefer != 0;
+  QltBox* b = new QltBox();
+  b->q.reset(new qlt::QLTHip(static_cast<ParallelBox*>(parallel)->p, ncells,
+                             static_cast<TreeBox*>(tree)->t, o));
+  b->ns.ns = &b->q->nodesets();
+  return b;
+  CEDR_CATCH(nullptr)
+}
+void cedr_qlt_free (void* h) { delete static_cast<QltBox*>(h); }
+int cedr_qlt_declare_tracer (void* h, int pt, int rhomidx) {
+  CEDR_TRY Q(h).declare_tracer(pt, rhomidx); return 0; CEDR_CATCH(-1)
+}
+int cedr_qlt_end_tracer_declarations (void* h) {
+  CEDR_TRY Q(h).end_tracer_declarations(); return 0; CEDR_CATCH(-1)
+}
+int cedr_qlt_get_buffers_sizes (void* h, size_t* b1, size_t* b2) {
+  CEDR_TRY Q(h).get_buffers_sizes(*b1, *b2); return 0; CEDR_CATCH(-1)
+}
+int cedr_qlt_set_buffers (void* h, double* b1, double* b2) {
+  CEDR_TRY Q(h).set_buffers(b1, b2); return 0; CEDR_CATCH(-1)
+}
+int cedr_qlt_finish_setup (void* h) { CEDR_TRY Q(h).finish_setup(); return 0; CEDR_CATCH(-1) }
+int cedr_qlt_get_problem_type (void* h, int ti) {
+  CEDR_TRY return Q(h).get_problem_type(ti); CEDR_CATCH(-1)
+}
+int cedr_qlt_get_num_tracers (void* h) { return Q(h).get_num_tracers(); }
+int cedr_qlt_nlclcells (void* h) { return Q(h).nlclcells(); }
+int cedr_qlt_get_owned_glblcells (void* h, long* gcis) {
+  CEDR_TRY
+  std::vector<Long> g;
+  Q(h).get_owned_glblcells(g);
+  std::copy(g.begin(), g.end(), gcis);
+  return 0;
+  CEDR_CATCH(-1)
+}
+int cedr_qlt_gci2lci (void* h, int gci) { CEDR_TRY return Q(h).gci2lci(gci); CEDR_CATCH(-1) }
+int cedr_qlt_run (void* h) { CEDR_TRY Q(h).run(); return 0; CEDR_CATCH(-1) }
+int cedr_qlt_set_stream (void* h, cedr_stream_t s) { Q(h).set_stream(s); return 0; }
+int cedr_qlt_get_device_op (void* h, cedr_qlt_device_op* out) {
+  const auto& o = Q(h).get_device_op();
+  out->l2r_data = o.l2r_data; out->r2l_data = o.r2l_data; out->stride = o.stride;
+  out->trcr2prob = o.trcr2prob; out->trcr2bl2r = o.trcr2bl2r; out->trcr2br2l = o.trcr2br2l;
+  return 0;
+}
+int cedr_qlt_set_rhom_bulk (void* h, const double* rhom) {
+  CEDR_TRY Q(h).set_rhom_bulk(rhom); return 0; CEDR_CATCH(-1)
+}
+int cedr_qlt_set_Qm_bulk (void* h, const double* Qm, const double* lo, const double* hi,
+                          const double* prev) {
+  CEDR_TRY Q(h).set_Qm_bulk(Qm, lo, hi, prev); return 0; CEDR_CATCH(-1)
+}
+int cedr_qlt_get_Qm_bulk (void* h, double* out) {
+  CEDR_TRY Q(h).get_Qm_bulk(out); return 0; CEDR_CATCH(-1)
+}
+int cedr_qlt_metadata (void* h, int* trcr2prob, int* bidx2trcr, int* trcr2bidx, int* trcr2bl2r,
+                       int* trcr2br2l, int* prob2trcrptr, int* prob2bl2r, int* prob2br2l) {
+  const auto& m = Q(h).metadata();
+  const size_t nt = m.trcr2prob.size();
+  for (size_t i = 0; i < nt; ++i) {
+    trcr2prob[i] = m.trcr2prob[i]; bidx2trcr[i] = m.bidx2trcr[i]; trcr2bidx[i] = m.trcr2bidx[i];
+    trcr2bl2r[i] = m.trcr2bl2r[i]; trcr2br2l[i] = m.trcr2br2l[i];
+  }
+  for (int i = 0; i < 7; ++i) {
+    prob2trcrptr[i] = m.prob2trcrptr[i]; prob2bl2r[i] = m.prob2bl2r[i]; prob2br2l[i] = m.prob2br2l[i];
+  }
+  return 0;
+}
+void* cedr_qlt_nodesets (void* h) { return &static_cast<QltBox*>(h)->ns; }
+
+// ----------------------------------------------------------------------- plan
+#define PL(h) (*static_cast<PlanBox*>(h)->p)
+
+void* cedr_plan_create (void* tree, int ncells, int my_rank, int nranks, int max_tile_leaves) {
+  CEDR_TRY
+  const tree::FlatTree& t = static_cast<TreeBox*>(tree)->t;
+  const auto ns = tree::analyze(my_rank, ncells, t);
+  cedr_throw_if(ns->levels.empty() || ns->levels[0].nodes.empty(), "0 cells on this rank");
+  std::map<Int,Int> g2l;
+  for (const Int idx : ns->levels[0].nodes) g2l[ns->node_h(idx)->id] = ns->node_h(idx)->offset;
+  std::vector<int32_t> leaf_slot(t.size(), -1);
+  for (Int n = 0; n < t.size(); ++n)
+    if (t.nkids[n] == 0 && t.rank[n] == my_rank) leaf_slot[n] = g2l.at(static_cast<Int>(t.cellidx[n]));
+  plan::Options o;
+  if (max_tile_leaves > 0) o.max_tile_leaves = max_tile_leaves;
+  PlanBox* b = new PlanBox();
+  b->owned = plan::build(t, my_rank, nranks, leaf_slot, o);
+  b->p = &b->owned;
+  b->stride = (static_cast<int64_t>(b->owned.nslots) + 15)/16*16;
+  return b;
+  CEDR_CATCH(nullptr)
+}
+void cedr_plan_free (void* h) { delete static_cast<PlanBox*>(h); }
+void* cedr_qlt_plan (void* h) {
+  QltBox* b = static_cast<QltBox*>(h);
+  b->plan.p = &b->q->tree_engine().get_plan();
+  b->plan.stride = b->q->tree_engine().stride();
+  return &b->plan;
+}
+
+int cedr_plan_summary (void* h, int64_t* s) {
+  const plan::Plan& p = PL(h);
+  s[0] = p.nlcl; s[1] = p.nslots; s[2] = static_cast<int64_t>(p.local.size());
+  s[3] = static_cast<int64_t>(p.top.size()); s[4] = p.root_slot; s[5] = p.nb_max;
+  s[6] = static_cast<int64_t>(p.my_root_slots.size()); s[7] = static_cast<PlanBox*>(h)->stride;
+  return 0;
+}
+static const plan::Stage* get_stage (void* h, int top, int idx) {
+  const plan::Plan& p = PL(h);
+  const auto& v = top ? p.top : p.local;
+  if (idx < 0 || idx >= static_cast<int>(v.size())) return nullptr;
+  return &v[idx];
+}
+int cedr_plan_stage_sizes (void* h, int top, int idx, int* sz) {
+  const plan::Stage* st = get_stage(h, top, idx);
+  if ( ! st) { g_err = "no such stage"; return -1; }
+  sz[0] = static_cast<int>(st->tiles.size()); sz[1] = st->max_nodes;
+  sz[2] = static_cast<int>(st->kids.size()/2); sz[3] = static_cast<int>(st->lvlptr.size());
+  return 0;
+}
+int cedr_plan_stage (void* h, int top, int idx, int* tiles, uint16_t* kids, int* lvlptr) {
+  const plan::Stage* st = get_stage(h, top, idx);
+  if ( ! st) { g_err = "no such stage"; return -1; }
+  std::memcpy(tiles, st->tiles.data(), st->tiles.size()*sizeof(plan::Tile));
+  std::copy(st->kids.begin(), st->kids.end(), kids);
+  std::copy(st->lvlptr.begin(), st->lvlptr.end(), lvlptr);
+  return 0;
+}
+int cedr_plan_exchange (void* h, int* my_root_slots, int* my_top_slots, int* gather_slots) {
+  const plan::Plan& p = PL(h);
+  std::copy(p.my_root_slots.begin(), p.my_root_slots.end(), my_root_slots);
+  std::copy(p.my_top_slots.begin(), p.my_top_slots.end(), my_top_slots);
+  std::copy(p.gather_slots.begin(), p.gather_slots.end(), gather_slots);
+  return 0;
+}
+
+// ----------------------------------------------------------------------- CAAS
+#define CA(h) (*static_cast<CaasBox*>(h)->c)
+void* cedr_caas_create (void* parallel, int nlclcells, cedr_user_allreduce_fn reducer,
+                        int nacc, void* user) {
+  CEDR_TRY
+  caas::CAASHip::UserAllReducer::Ptr r;
+  if (reducer) r = std::make_shared<CbReducer>(reducer, nacc < 1 ? 1 : nacc, user);
+  CaasBox* b = new CaasBox();
+  b->c.reset(new caas::CAASHip(static_cast<ParallelBox*>(parallel)->p, nlclcells, r));
+  return b;
+  CEDR_CATCH(nullptr)
+}
+void cedr_caas_free (void* h) { delete static_cast<CaasBox*>(h); }
+int cedr_caas_declare_tracer (void* h, int pt, int rhomidx) {
+  CEDR_TRY CA(h).declare_tracer(pt, rhomidx); return 0; CEDR_CATCH(-1)
+}
+int cedr_caas_end_tracer_declarations (void* h) {
+  CEDR_TRY CA(h).end_tracer_declarations(); return 0; CEDR_CATCH(-1)
+}
+int cedr_caas_get_buffers_sizes (void* h, size_t* b1, size_t* b2) {
+  CEDR_TRY CA(h).get_buffers_sizes(*b1, *b2); return 0; CEDR_CATCH(-1)
+}
+int cedr_caas_set_buffers (void* h, double* b1, double* b2) {
+  CEDR_TRY CA(h).set_buffers(b1, b2); return 0; CEDR_CATCH(-1)
+}
+int cedr_caas_finish_setup (void* h) { CEDR_TRY CA(h).finish_setup(); return 0; CEDR_CATCH(-1) }
+int cedr_caas_get_problem_type (void* h, int ti) {
+  CEDR_TRY return CA(h).get_problem_type(ti); CEDR_CATCH(-1)
+}
+int cedr_caas_get_num_tracers (void* h) { return CA(h).get_num_tracers(); }
+int cedr_caas_run (void* h) { CEDR_TRY CA(h).run(); return 0; CEDR_CATCH(-1) }
+int cedr_caas_set_stream (void* h, cedr_stream_t s) { CA(h).set_stream(s); return 0; }
+int cedr_caas_set_Qm_source (void* h, const double* src) { CA(h).set_Qm_source(src); return 0; }
+int cedr_caas_get_device_op (void* h, cedr_caas_device_op* out) {
+  const auto& o = CA(h).get_device_op();
+  out->d = o.d_; out->nlclcells = o.nlclcells_; out->nt = o.nt_;
+  out->need_conserve = o.need_conserve_;
+  return 0;
+}
+int cedr_caas_get_recv (void* h, const double** recv) { *recv = CA(h).recv_data(); return 0; }
+
+// ------------------------------------------------------------------------ BFB
+void* cedr_bfb_create (void* parallel, void* tree, int nleaf, int nfield) {
+  CEDR_TRY
+  BfbBox* b = new BfbBox();
+  b->b.reset(new BfbTreeAllReducerHip(static_cast<ParallelBox*>(parallel)->p,
+                                      static_cast<TreeBox*>(tree)->t, nleaf, nfield));
+  return b;
+  CEDR_CATCH(nullptr)
+}
+void cedr_bfb_free (void* h) { delete static_cast<BfbBox*>(h); }
+int cedr_bfb_nlocal (void* h) { return static_cast<BfbBox*>(h)->b->nlocal(); }
+int cedr_bfb_allreduce (void* h, const double* send, double* recv, int transpose) {
+  CEDR_TRY static_cast<BfbBox*>(h)->b->allreduce(send, recv, transpose != 0); return 0; CEDR_CATCH(-1)
+}
+
+// -------------------------------------------------------------- device helpers
+int cedr_device_count (void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+void* cedr_malloc (size_t bytes) {
+  void* p = nullptr;
+  if (hipMalloc(&p, bytes) != hipSuccess) { g_err = "hipMalloc failed"; return nullptr; }
+  return p;
+}
+void cedr_free (void* p) { (void) hipFree(p); }
+int cedr_memcpy_h2d (void* d, const void* s, size_t n) {
+  return static_cast<int>(hipMemcpy(d, s, n, hipMemcpyHostToDevice));
+}
+int cedr_memcpy_d2h (void* d, const void* s, size_t n) {
+  return static_cast<int>(hipMemcpy(d, s, n, hipMemcpyDeviceToHost));
+}
+int cedr_memcpy_d2d_async (void* d, const void* s, size_t n, cedr_stream_t st) {
+  return static_cast<int>(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, st));
+}
+int cedr_device_synchronize (void) { return static_cast<int>(hipDeviceSynchronize()); }
+
+}  // extern "C"

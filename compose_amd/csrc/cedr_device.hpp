@@ -1,0 +1,46 @@
+// Small RAII helpers over hipMalloc/hipMemcpy for the host classes.
+#ifndef COMPOSE_AMD_CEDR_DEVICE_HPP
+#define COMPOSE_AMD_CEDR_DEVICE_HPP
+
+#include <hip/hip_runtime.h>
+
+#include <vector>
+
+#include "cedr_util.hpp"
+
+namespace cedr {
+namespace dev {
+
+template <typename T>
+class Buffer {
+  T* p_ = nullptr;
+  size_t n_ = 0;
+public:
+  Buffer () {}
+  Buffer (const Buffer&) = delete;
+  Buffer& operator= (const Buffer&) = delete;
+  ~Buffer () { release(); }
+  void release () { if (p_) (void) hipFree(p_); p_ = nullptr; n_ = 0; }
+  void alloc (size_t n) {
+    release();
+    n_ = n;
+    if (n == 0) return;
+    cedr_hip_check(hipMalloc(reinterpret_cast<void**>(&p_), n*sizeof(T)));
+  }
+  void alloc_zero (size_t n) {
+    alloc(n);
+    if (n) cedr_hip_check(hipMemset(p_, 0, n*sizeof(T)));
+  }
+  void upload (const std::vector<T>& h) {
+    alloc(h.size());
+    if ( ! h.empty())
+      cedr_hip_check(hipMemcpy(p_, h.data(), h.size()*sizeof(T), hipMemcpyHostToDevice));
+  }
+  T* data () const { return p_; }
+  size_t size () const { return n_; }
+};
+
+}  // namespace dev
+}  // namespace cedr
+
+#endif

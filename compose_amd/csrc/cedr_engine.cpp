@@ -1,0 +1,96 @@
+#include "cedr_engine.hpp"
+
+#include <map>
+
+namespace cedr {
+namespace engine {
+
+#define cedr_k_check(call) do {                                         \
+    const int _e_ = (call);                                             \
+    cedr_throw_if(_e_ != 0, "kernel launch failed with HIP error " << _e_ << " in " #call); \
+  } while (0)
+
+void DeviceStage::upload (const plan::Stage& st) {
+  static_assert(sizeof(plan::Tile) == sizeof(cedr_hip_tile), "tile layouts must agree");
+  std::vector<cedr_hip_tile> tl(st.tiles.size());
+  for (size_t i = 0; i < tl.size(); ++i) {
+    const plan::Tile& s = st.tiles[i];
+    tl[i] = cedr_hip_tile{s.in0, s.nleaf, s.out, s.nint, s.kids_off, s.lvl_off, s.nlvl, 0};
+  }
+  tiles.upload(tl);
+  kids.upload(st.kids);
+  lvlptr.upload(st.lvlptr);
+  h.ntiles = static_cast<int32_t>(st.tiles.size());
+  h.max_nodes = st.max_nodes;
+  h.max_nint = st.max_nint;
+  h.pad = 0;
+  h.tiles = tiles.data();
+  h.kids = kids.data();
+  h.lvlptr = lvlptr.data();
+}
+
+TreeEngine::TreeEngine (const mpi::Parallel::Ptr& p, const tree::FlatTree& t,
+                        const tree::NodeSets& ns, const plan::Options& opt)
+  : p_(p)
+{
+  // Local cell index of every owned leaf = its NodeSets offset (the reference's
+  // numbering, visible to callers through get_owned_glblcells).
+  std::map<Int,Int> gci2lci;
+  for (const Int idx : ns.levels[0].nodes) gci2lci[ns.node_h(idx)->id] = ns.node_h(idx)->offset;
+  std::vector<int32_t> leaf_slot(t.size(), -1);
+  const Int me = p->rank();
+  for (Int n = 0; n < t.size(); ++n)
+    if (t.nkids[n] == 0 && t.rank[n] == me) {
+      const auto it = gci2lci.find(static_cast<Int>(t.cellidx[n]));
+      cedr_throw_if(it == gci2lci.end(), "owned leaf " << t.cellidx[n] << " missing from NodeSets");
+      leaf_slot[n] = it->second;
+    }
+  plan_ = plan::build(t, me, p->size(), leaf_slot, opt);
+  stride_ = (static_cast<int64_t>(plan_.nslots) + 15)/16*16;
+  for (const auto& st : plan_.local) {
+    local_.emplace_back(new DeviceStage());
+    local_.back()->upload(st);
+  }
+  for (const auto& st : plan_.top) {
+    top_.emplace_back(new DeviceStage());
+    top_.back()->upload(st);
+  }
+  if ( ! plan_.top.empty()) {
+    my_root_slots_.upload(plan_.my_root_slots);
+    my_top_slots_.upload(plan_.my_top_slots);
+    gather_slots_.upload(plan_.gather_slots);
+  }
+}
+
+void TreeEngine::up (int32_t nfields, const uint8_t* op_dev, double* data, bool zero_init,
+                     hipStream_t stream) {
+  for (const auto& st : local_)
+    cedr_k_check(cedr_hip_tree_up(&st->h, nfields, op_dev, stride_, data, zero_init, stream));
+  if (top_.empty()) return;
+  const int32_t P = plan_.nranks, nb = plan_.nb_max;
+  if (nfields > xfields_) {
+    sendbuf_.alloc_zero(static_cast<size_t>(nb)*nfields);
+    recvbuf_.alloc_zero(static_cast<size_t>(P)*nb*nfields);
+    xfields_ = nfields;
+  }
+  cedr_k_check(cedr_hip_gather_slots(data, stride_, nfields, my_root_slots_.data(),
+                                     static_cast<int32_t>(plan_.my_root_slots.size()),
+                                     sendbuf_.data(), stream));
+  const int err = p_->comm()->allgather(sendbuf_.data(), recvbuf_.data(),
+                                        static_cast<size_t>(nb)*nfields, stream);
+  cedr_throw_if(err != 0, "allgather of subtree roots returned " << err);
+  cedr_k_check(cedr_hip_scatter_slots(data, stride_, nfields, gather_slots_.data(), P*nb,
+                                      recvbuf_.data(), stream));
+  for (const auto& st : top_)
+    cedr_k_check(cedr_hip_tree_up(&st->h, nfields, op_dev, stride_, data, zero_init, stream));
+}
+
+void TreeEngine::top_to_local (int32_t nfields, double* data, hipStream_t stream) {
+  if (top_.empty()) return;
+  cedr_k_check(cedr_hip_copy_slots(data, stride_, nfields, my_top_slots_.data(),
+                                   my_root_slots_.data(),
+                                   static_cast<int32_t>(plan_.my_root_slots.size()), stream));
+}
+
+}  // namespace engine
+}  // namespace cedr

@@ -1,0 +1,61 @@
+// Device-resident form of a plan::Plan plus the leaves->root driver shared by
+// QLT and BfbTreeAllReducer: local stages, ONE all-gather of the pure
+// subtrees' root records, replicated top stages.
+#ifndef COMPOSE_AMD_CEDR_ENGINE_HPP
+#define COMPOSE_AMD_CEDR_ENGINE_HPP
+
+#include <memory>
+#include <vector>
+
+#include "../../include/cedr_hip.h"
+#include "cedr_device.hpp"
+#include "cedr_plan.hpp"
+
+namespace cedr {
+namespace engine {
+
+struct DeviceStage {
+  dev::Buffer<cedr_hip_tile> tiles;
+  dev::Buffer<uint16_t> kids;
+  dev::Buffer<int32_t> lvlptr;
+  cedr_hip_stage h;
+  void upload(const plan::Stage& st);
+};
+
+class TreeEngine {
+public:
+  TreeEngine(const mpi::Parallel::Ptr& p, const tree::FlatTree& t, const tree::NodeSets& ns,
+             const plan::Options& opt);
+
+  const plan::Plan& get_plan () const { return plan_; }
+  // Doubles between consecutive fields: the plan's slot count rounded up to a
+  // multiple of 16 so that every field row starts on a 128-byte line.
+  int64_t stride () const { return stride_; }
+  int32_t nslots () const { return plan_.nslots; }
+
+  // Leaves->root over 'nfields' fields of 'data' (field-major, stride()).
+  // After it returns (stream ordered) data[f*stride + root_slot] holds the
+  // global root's record on every rank.
+  void up(int32_t nfields, const uint8_t* op_dev, double* data, bool zero_init,
+          hipStream_t stream);
+
+  const std::vector<std::unique_ptr<DeviceStage> >& local_stages () const { return local_; }
+  const std::vector<std::unique_ptr<DeviceStage> >& top_stages () const { return top_; }
+  // Copy 'nfields' fields of my boundary roots from their top-stage input
+  // slots to their local slots (root->leaves direction).
+  void top_to_local(int32_t nfields, double* data, hipStream_t stream);
+
+private:
+  mpi::Parallel::Ptr p_;
+  plan::Plan plan_;
+  int64_t stride_;
+  std::vector<std::unique_ptr<DeviceStage> > local_, top_;
+  dev::Buffer<int32_t> my_root_slots_, my_top_slots_, gather_slots_;
+  dev::Buffer<double> sendbuf_, recvbuf_;
+  int32_t xfields_ = 0;
+};
+
+}  // namespace engine
+}  // namespace cedr
+
+#endif

@@ -1,0 +1,138 @@
+// Communicator backends behind cedr::mpi::Parallel (see cedr_mpi.hpp).
+#include "cedr_mpi.hpp"
+
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <mutex>
+
+#include "cedr_util.hpp"
+
+namespace cedr {
+namespace mpi {
+namespace {
+
+// ------------------------------------------------------------------ single rank
+struct SelfComm : public Comm {
+  int rank () const override { return 0; }
+  int size () const override { return 1; }
+  int allgather (const Real* send, Real* recv, size_t count, hipStream_t s) override {
+    if (send == recv || count == 0) return 0;
+    return static_cast<int>(hipMemcpyAsync(recv, send, count*sizeof(Real),
+                                           hipMemcpyDeviceToDevice, s));
+  }
+  int allreduce_sum (const Real* send, Real* recv, size_t count, hipStream_t s) override {
+    return allgather(send, recv, count, s);
+  }
+};
+
+// ------------------------------------------------------------------------ RCCL
+// Resolved at run time so that the library loads on machines without RCCL and
+// shares whichever librccl the process already has (PyTorch ships its own).
+struct ncclUniqueIdBlob { char internal[128]; };
+typedef void* ncclComm_t;
+enum { kNcclSuccess = 0, kNcclSum = 0, kNcclFloat64 = 8 };
+
+struct RcclApi {
+  int (*GetUniqueId)(ncclUniqueIdBlob*);
+  int (*CommInitRank)(ncclComm_t*, int, ncclUniqueIdBlob, int);
+  int (*CommDestroy)(ncclComm_t);
+  int (*AllGather)(const void*, void*, size_t, int, ncclComm_t, hipStream_t);
+  int (*AllReduce)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t);
+  bool ok;
+};
+
+const RcclApi& rccl () {
+  static RcclApi api;
+  static std::once_flag once;
+  std::call_once(once, [] () {
+    api.ok = false;
+    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (size_t i = 0; ! h && i < sizeof(names)/sizeof(*names); ++i)
+      h = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
+    if ( ! h) return;
+    api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
+    api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
+    api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+    api.AllGather = reinterpret_cast<decltype(api.AllGather)>(dlsym(h, "ncclAllGather"));
+    api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(dlsym(h, "ncclAllReduce"));
+    api.ok = api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.AllGather &&
+      api.AllReduce;
+  });
+  return api;
+}
+
+struct RcclComm : public Comm {
+  ncclComm_t comm_;
+  int rank_, size_;
+  RcclComm (const void* id, int rank, int size) : comm_(nullptr), rank_(rank), size_(size) {
+    const RcclApi& a = rccl();
+    cedr_throw_if( ! a.ok, "librccl could not be loaded");
+    ncclUniqueIdBlob blob;
+    std::memcpy(&blob, id, sizeof(blob));
+    const int e = a.CommInitRank(&comm_, size, blob, rank);
+    cedr_throw_if(e != kNcclSuccess, "ncclCommInitRank returned " << e);
+  }
+  ~RcclComm () override { if (comm_) rccl().CommDestroy(comm_); }
+  int rank () const override { return rank_; }
+  int size () const override { return size_; }
+  int allgather (const Real* send, Real* recv, size_t count, hipStream_t s) override {
+    return rccl().AllGather(send, recv, count, kNcclFloat64, comm_, s);
+  }
+  int allreduce_sum (const Real* send, Real* recv, size_t count, hipStream_t s) override {
+    return rccl().AllReduce(send, recv, count, kNcclFloat64, kNcclSum, comm_, s);
+  }
+};
+
+// -------------------------------------------------------------------- callbacks
+struct CallbackComm : public Comm {
+  int rank_, size_;
+  AllgatherFn ag_;
+  AllreduceSumFn ar_;
+  void* user_;
+  CallbackComm (int r, int s, AllgatherFn ag, AllreduceSumFn ar, void* u)
+    : rank_(r), size_(s), ag_(ag), ar_(ar), user_(u) {}
+  int rank () const override { return rank_; }
+  int size () const override { return size_; }
+  int allgather (const Real* send, Real* recv, size_t count, hipStream_t s) override {
+    return ag_(user_, send, recv, count, s);
+  }
+  int allreduce_sum (const Real* send, Real* recv, size_t count, hipStream_t s) override {
+    return ar_(user_, send, recv, count, s);
+  }
+};
+
+}  // namespace
+
+Parallel::Ptr make_parallel () {
+  return std::make_shared<Parallel>(std::make_shared<SelfComm>());
+}
+
+Parallel::Ptr make_parallel (const std::shared_ptr<Comm>& comm) {
+  return std::make_shared<Parallel>(comm);
+}
+
+int rccl_get_unique_id (void* unique_id_128B) {
+  const RcclApi& a = rccl();
+  if ( ! a.ok) return -1;
+  ncclUniqueIdBlob blob;
+  const int e = a.GetUniqueId(&blob);
+  if (e != kNcclSuccess) return e;
+  std::memcpy(unique_id_128B, &blob, sizeof(blob));
+  return 0;
+}
+
+Parallel::Ptr make_parallel_rccl (const void* unique_id_128B, int rank, int size) {
+  return std::make_shared<Parallel>(std::make_shared<RcclComm>(unique_id_128B, rank, size));
+}
+
+Parallel::Ptr make_parallel_callbacks (int rank, int size, AllgatherFn ag, AllreduceSumFn ar,
+                                       void* user) {
+  cedr_throw_if( ! ag || ! ar, "null collective callback");
+  return std::make_shared<Parallel>(std::make_shared<CallbackComm>(rank, size, ag, ar, user));
+}
+
+}  // namespace mpi
+}  // namespace cedr

@@ -1,0 +1,64 @@
+// cedr::mpi::Parallel -- the communicator handle every CDR takes, as in
+// reference cedr/cedr_mpi.hpp:17-27 (Parallel: comm(), size(), rank(), root(),
+// amroot()). The reference wraps an MPI_Comm and moves device pointers with
+// MPI point-to-point messages per tree level (cedr_qlt.cpp:327-337,432-439).
+// Here a Parallel wraps a Comm: a stream-ordered collective backend over
+// DEVICE buffers. One process per GPU; the built-in backend is RCCL over xGMI.
+// A callback backend lets a host application plug in its own transport (MPI
+// with GPU-aware pointers, or a host-staged one) without this library linking it.
+#ifndef COMPOSE_AMD_CEDR_MPI_HPP
+#define COMPOSE_AMD_CEDR_MPI_HPP
+
+#include <memory>
+
+#include "cedr.hpp"
+
+typedef struct ihipStream_t* hipStream_t;
+
+namespace cedr {
+namespace mpi {
+
+// Collective backend. All buffers are device memory; every call is enqueued on
+// (or ordered with respect to) 'stream' and returns 0 on success.
+struct Comm {
+  virtual ~Comm () {}
+  virtual int rank () const = 0;
+  virtual int size () const = 0;
+  // recv[r*count : (r+1)*count] = rank r's send[0:count], for every r.
+  virtual int allgather (const Real* send, Real* recv, size_t count, hipStream_t stream) = 0;
+  // recv[i] = sum over ranks of send[i]. send and recv may alias.
+  virtual int allreduce_sum (const Real* send, Real* recv, size_t count, hipStream_t stream) = 0;
+};
+
+class Parallel {
+  std::shared_ptr<Comm> comm_;
+public:
+  typedef std::shared_ptr<Parallel> Ptr;
+  explicit Parallel (const std::shared_ptr<Comm>& comm) : comm_(comm) {}
+  const std::shared_ptr<Comm>& comm () const { return comm_; }
+  Int size () const { return comm_->size(); }
+  Int rank () const { return comm_->rank(); }
+  Int root () const { return 0; }
+  bool amroot () const { return rank() == root(); }
+};
+
+// Single-rank communicator (the reference's MPI_COMM_SELF use case).
+Parallel::Ptr make_parallel ();
+Parallel::Ptr make_parallel (const std::shared_ptr<Comm>& comm);
+
+// RCCL communicator. 'unique_id' is the 128-byte ncclUniqueId produced by
+// rccl_get_unique_id on one rank and distributed by the launcher (bench.py uses
+// torch.distributed for that). librccl is dlopen'ed on first use.
+int rccl_get_unique_id (void* unique_id_128B);
+Parallel::Ptr make_parallel_rccl (const void* unique_id_128B, int rank, int size);
+
+// Callback communicator: the host application supplies the two collectives.
+typedef int (*AllgatherFn) (void* user, const Real* send, Real* recv, size_t count, hipStream_t);
+typedef int (*AllreduceSumFn) (void* user, const Real* send, Real* recv, size_t count, hipStream_t);
+Parallel::Ptr make_parallel_callbacks (int rank, int size, AllgatherFn ag, AllreduceSumFn ar,
+                                       void* user);
+
+}  // namespace mpi
+}  // namespace cedr
+
+#endif

@@ -1,0 +1,209 @@
+// Builds the tile/stage plan described in cedr_plan.hpp. Pure host integer work.
+#include "cedr_plan.hpp"
+
+#include <algorithm>
+
+#include "cedr_util.hpp"
+
+namespace cedr {
+namespace plan {
+namespace {
+
+struct Builder {
+  const tree::FlatTree& t;
+  const Options opt;
+  std::vector<int32_t> slot;   // per tree node: slot of its record once it is an input
+  std::vector<int32_t> cnt;    // scratch: # current inputs below a node
+  std::vector<int32_t> lid;    // scratch: local id inside the tile being built
+  std::vector<int32_t> llvl;   // scratch: local level inside the tile being built
+  int32_t next_slot;
+
+  Builder (const tree::FlatTree& t_, const Options& o)
+    : t(t_), opt(o), slot(t_.size(), -1), cnt(t_.size(), 0), lid(t_.size(), -1),
+      llvl(t_.size(), 0), next_slot(0) {}
+
+  // cnt[n] for every node reachable from r without passing through an input.
+  void count_inputs (const int32_t r) {
+    std::vector<std::pair<int32_t,int32_t> > st;
+    st.push_back(std::make_pair(r, 0));
+    while ( ! st.empty()) {
+      auto& top = st.back();
+      const int32_t n = top.first;
+      if (slot[n] >= 0) { cnt[n] = 1; st.pop_back(); continue; }
+      if (top.second < 2) {
+        const int32_t k = t.kid(n, top.second++);
+        st.push_back(std::make_pair(k, 0));
+      } else {
+        cnt[n] = cnt[t.kid0[n]] + cnt[t.kid1[n]];
+        st.pop_back();
+      }
+    }
+  }
+
+  // Append the tile rooted at tree node r to st. Inputs are the nodes with
+  // slot >= 0 met by the DFS, in DFS order; their slots must be consecutive.
+  void build_tile (Stage& st, const int32_t r) {
+    Tile tile;
+    tile.pad = 0;
+    tile.kids_off = static_cast<int32_t>(st.kids.size()/2);
+    tile.lvl_off = static_cast<int32_t>(st.lvlptr.size());
+    tile.out = next_slot++;
+    std::vector<int32_t> internals;  // post-order
+    int32_t nleaf = 0, in0 = -1;
+    {
+      std::vector<std::pair<int32_t,int32_t> > stack;
+      stack.push_back(std::make_pair(r, 0));
+      while ( ! stack.empty()) {
+        auto& top = stack.back();
+        const int32_t n = top.first;
+        if (slot[n] >= 0) {
+          if (nleaf == 0) in0 = slot[n];
+          cedr_throw_if(slot[n] != in0 + nleaf,
+                        "The local cell order does not keep each owned subtree's cells "
+                        "contiguous; this ordering is not supported yet.");
+          lid[n] = nleaf++;
+          llvl[n] = 0;
+          stack.pop_back();
+          continue;
+        }
+        if (top.second < 2) {
+          const int32_t k = t.kid(n, top.second++);
+          stack.push_back(std::make_pair(k, 0));
+        } else {
+          llvl[n] = 1 + std::max(llvl[t.kid0[n]], llvl[t.kid1[n]]);
+          internals.push_back(n);
+          stack.pop_back();
+        }
+      }
+    }
+    tile.in0 = in0;
+    tile.nleaf = nleaf;
+    tile.nint = static_cast<int32_t>(internals.size());
+    cedr_throw_if(tile.nleaf + tile.nint > 65535, "tile too large for 16-bit local ids");
+    // Kids before parents: order internal nodes by local level, DFS order within.
+    std::stable_sort(internals.begin(), internals.end(),
+                     [&] (int32_t a, int32_t b) { return llvl[a] < llvl[b]; });
+    for (size_t i = 0; i < internals.size(); ++i)
+      lid[internals[i]] = nleaf + static_cast<int32_t>(i);
+    // lvlptr: start offsets of each local level's internal nodes, then nint.
+    tile.nlvl = 0;
+    st.lvlptr.push_back(0);
+    for (size_t i = 0; i < internals.size(); ++i) {
+      const int32_t n = internals[i];
+      if (i > 0 && llvl[n] != llvl[internals[i-1]]) {
+        st.lvlptr.push_back(static_cast<int32_t>(i));
+        ++tile.nlvl;
+      }
+      st.kids.push_back(static_cast<uint16_t>(lid[t.kid0[n]]));
+      st.kids.push_back(static_cast<uint16_t>(lid[t.kid1[n]]));
+    }
+    if ( ! internals.empty()) { st.lvlptr.push_back(tile.nint); ++tile.nlvl; }
+    st.max_nodes = std::max(st.max_nodes, tile.nleaf + tile.nint);
+    st.max_nint = std::max(st.max_nint, tile.nint);
+    st.tiles.push_back(tile);
+    pending.push_back(std::make_pair(r, tile.out));
+  }
+
+  std::vector<std::pair<int32_t,int32_t> > pending;  // (tile root, out slot) of the stage
+
+  // Reduce every root in 'roots' to a single input slot, appending stages.
+  void tile_forest (const std::vector<int32_t>& roots, std::vector<Stage>& stages) {
+    for (;;) {
+      std::vector<int32_t> active;
+      for (const int32_t r : roots) if (slot[r] < 0) active.push_back(r);
+      if (active.empty()) break;
+      for (const int32_t r : active) count_inputs(r);
+      Stage st;
+      pending.clear();
+      std::vector<int32_t> stack(active.rbegin(), active.rend());
+      while ( ! stack.empty()) {
+        const int32_t n = stack.back();
+        stack.pop_back();
+        if (slot[n] >= 0 || cnt[n] <= opt.max_tile_leaves) {
+          // An input hanging directly off a too-large node becomes a 1-input
+          // tile (a copy) so that the next stage's inputs stay contiguous.
+          build_tile(st, n);
+        } else {
+          stack.push_back(t.kid1[n]);
+          stack.push_back(t.kid0[n]);
+        }
+      }
+      for (const auto& p : pending) slot[p.first] = p.second;
+      stages.push_back(std::move(st));
+    }
+  }
+};
+
+}  // namespace
+
+Plan build (const tree::FlatTree& t, int32_t my_rank, int32_t nranks,
+            const std::vector<int32_t>& leaf_slot, const Options& opt) {
+  const int32_t nn = t.size();
+  cedr_throw_if(opt.max_tile_leaves < 2, "max_tile_leaves must be >= 2");
+  Plan p;
+  p.my_rank = my_rank;
+  p.nranks = nranks;
+
+  // own[n]: the rank owning every leaf below n, or -1 if more than one does.
+  std::vector<int32_t> own(nn, -1);
+  for (const Int n : tree::post_order(t)) {
+    if (t.nkids[n] == 0) {
+      cedr_throw_if(t.rank[n] < 0 || t.rank[n] >= nranks, "leaf rank out of range");
+      own[n] = t.rank[n];
+    } else {
+      cedr_throw_if(t.nkids[n] != 2, "Only binary trees are supported: a node has "
+                    << t.nkids[n] << " kids.");
+      const int32_t a = own[t.kid0[n]], b = own[t.kid1[n]];
+      own[n] = (a >= 0 && a == b) ? a : -1;
+    }
+    cedr_throw_if(t.level[n] >= 0, "Partial trees (Node::level) are not supported by this build.");
+  }
+
+  // Boundary roots = roots of maximal single-rank subtrees, in DFS order.
+  std::vector<int32_t> broots;
+  {
+    std::vector<int32_t> stack(1, 0);
+    while ( ! stack.empty()) {
+      const int32_t n = stack.back();
+      stack.pop_back();
+      if (own[n] >= 0) { broots.push_back(n); continue; }
+      stack.push_back(t.kid1[n]);
+      stack.push_back(t.kid0[n]);
+    }
+  }
+
+  Builder b(t, opt);
+  for (int32_t n = 0; n < nn; ++n)
+    if (t.nkids[n] == 0 && t.rank[n] == my_rank) {
+      cedr_throw_if(leaf_slot[n] < 0, "owned leaf without a local index");
+      b.slot[n] = leaf_slot[n];
+      ++p.nlcl;
+    }
+  b.next_slot = p.nlcl;
+
+  std::vector<int32_t> my_roots;
+  for (const int32_t r : broots) if (own[r] == my_rank) my_roots.push_back(r);
+  b.tile_forest(my_roots, p.local);
+  for (const int32_t r : my_roots) p.my_root_slots.push_back(b.slot[r]);
+
+  if (broots.size() > 1) {
+    std::vector<int32_t> per_rank(nranks, 0);
+    for (const int32_t r : broots) ++per_rank[own[r]];
+    p.nb_max = *std::max_element(per_rank.begin(), per_rank.end());
+    p.gather_slots.assign(static_cast<size_t>(nranks)*p.nb_max, -1);
+    std::fill(per_rank.begin(), per_rank.end(), 0);
+    for (const int32_t r : broots) {
+      const int32_t ts = b.next_slot++;
+      b.slot[r] = ts;
+      p.gather_slots[static_cast<size_t>(own[r])*p.nb_max + per_rank[own[r]]++] = ts;
+      if (own[r] == my_rank) p.my_top_slots.push_back(ts);
+    }
+    b.tile_forest(std::vector<int32_t>(1, 0), p.top);
+  }
+  p.root_slot = b.slot[0];
+  p.nslots = b.next_slot;
+  return p;
+}
+
+}  // namespace plan
+}  // namespace cedr

@@ -1,0 +1,80 @@
+// Execution plan for tree sweeps on MI355X.
+//
+// The reference walks the tree one level per kernel launch with every node's
+// record in global memory (cedr_qlt.cpp:339-430, 525-604) and exchanges one
+// MPI message per (level, partner rank). This build instead cuts the tree into
+// TILES -- subtrees small enough for one workgroup to hold in LDS -- and runs
+// a few STAGES: stage 1 tiles sit on the leaf cells, the roots of stage-k tiles
+// are the "leaves" of stage k+1. Only tile roots ever touch HBM besides the
+// leaves themselves. Ranks own whole subtrees ("pure" subtrees: every leaf on
+// one rank); the part of the tree above them is small, is replicated on every
+// rank, and is fed by ONE all-gather of the pure subtrees' root records.
+//
+// Every node still computes exactly the reference's expression on exactly the
+// reference's operands, so results are bit-identical whatever the tiling and
+// whatever the rank count.
+#ifndef COMPOSE_AMD_CEDR_PLAN_HPP
+#define COMPOSE_AMD_CEDR_PLAN_HPP
+
+#include <cstdint>
+#include <vector>
+
+#include "cedr_tree.hpp"
+
+namespace cedr {
+namespace plan {
+
+// One tile = one subtree handled by one workgroup. Input slots are contiguous.
+// Local node numbering inside a tile: inputs 0..nleaf-1 in slot order, then
+// internal nodes nleaf..nleaf+nint-1 ordered by local level (kids before
+// parents); the tile root is the last node (or input 0 if nint == 0).
+struct Tile {
+  int32_t in0;       // first input slot
+  int32_t nleaf;     // number of input slots
+  int32_t out;       // slot the tile root's record is written to / read from
+  int32_t nint;      // number of internal nodes
+  int32_t kids_off;  // offset of this tile's first internal node in Stage::kids (pairs)
+  int32_t lvl_off;   // offset into Stage::lvlptr
+  int32_t nlvl;      // number of local levels of internal nodes
+  int32_t pad;
+};
+
+struct Stage {
+  std::vector<Tile> tiles;
+  std::vector<uint16_t> kids;   // 2 local node ids per internal node
+  std::vector<int32_t> lvlptr;  // per tile: nlvl+1 prefix offsets over its internal nodes
+  int32_t max_nodes = 0;        // max over tiles of nleaf + nint
+  int32_t max_nint = 0;
+};
+
+struct Plan {
+  int32_t my_rank = 0, nranks = 1;
+  int32_t nlcl = 0;       // cells owned by this rank; their slots are 0..nlcl-1 in
+                          // the reference's local cell order (NodeSets leaf offsets)
+  int32_t nslots = 0;     // slots used by this plan
+  std::vector<Stage> local;  // stages over this rank's pure subtrees, leaf-most first
+  std::vector<Stage> top;    // replicated stages above the pure subtrees (empty if 1 rank)
+  int32_t root_slot = 0;     // slot of the global root's record on this rank
+
+  // Boundary exchange (unused when nranks == 1). A boundary root is the root
+  // of a maximal pure subtree.
+  int32_t nb_max = 0;                    // max # boundary roots on any rank
+  std::vector<int32_t> my_root_slots;    // slots of my boundary roots, my DFS order
+  std::vector<int32_t> my_top_slots;     // the same roots' slots as inputs of 'top'
+  std::vector<int32_t> gather_slots;     // [nranks*nb_max] top input slot of rank r's
+                                         // j-th boundary root, or -1 for padding
+};
+
+struct Options {
+  int32_t max_tile_leaves = 256;  // inputs per tile (bounded by the kernels' LDS use)
+};
+
+// 'leaf_slot[n]' gives, for every tree node n that is a leaf owned by my_rank,
+// its local cell index (NodeSets offset); -1 elsewhere.
+Plan build(const tree::FlatTree& t, int32_t my_rank, int32_t nranks,
+           const std::vector<int32_t>& leaf_slot, const Options& opt);
+
+}  // namespace plan
+}  // namespace cedr
+
+#endif

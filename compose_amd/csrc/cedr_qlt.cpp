@@ -1,0 +1,279 @@
+// Host side of QLT for MI355X. Setup mirrors reference cedr/cedr_qlt.cpp
+// (cited per function); run() drives the tile/stage kernels instead of the
+// reference's per-level launch + fence + MPI loop (cedr_qlt.cpp:618-640).
+#include "cedr_qlt.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdlib>
+
+#include "../../include/cedr_hip.h"
+#include "cedr_device.hpp"
+#include "cedr_engine.hpp"
+#include "cedr_util.hpp"
+
+namespace cedr {
+namespace qlt {
+
+#define cedr_k_check(call) do {                                         \
+    const int _e_ = (call);                                             \
+    cedr_throw_if(_e_ != 0, "kernel launch failed with HIP error " << _e_ << " in " #call); \
+  } while (0)
+
+struct QLTHip::Impl {
+  hipStream_t stream = nullptr;
+  bool inited = false;
+  Real* l2r = nullptr;
+  Real* r2l = nullptr;
+  dev::Buffer<Real> l2r_own, r2l_own;
+  // Tracer tables on the device: caller order (DeviceOp, bulk pack) and bulk order (kernels).
+  dev::Buffer<Int> trcr2prob, trcr2bl2r, trcr2br2l, bidx_prob, bidx_l2r, bidx_r2l;
+  dev::Buffer<uint8_t> l2r_op;
+  cedr_hip_qlt_layout lay;
+};
+
+// ---- MetaData: reference cedr_qlt.cpp:85-157, cedr_qlt_inl.hpp:101-117 ----
+int QLTHip::MetaData::get_problem_type (const int& idx) {
+  static const Int problem_type[] = { CPT::st, CPT::cst, CPT::t, CPT::ct, CPT::nn, CPT::cnn };
+  return problem_type[idx];
+}
+
+int QLTHip::MetaData::get_problem_type_idx (const int& mask) {
+  switch (mask) {
+  case CPT::s:   case CPT::st:  return 0;
+  case CPT::cs:  case CPT::cst: return 1;
+  case CPT::t:   return 2;
+  case CPT::ct:  return 3;
+  case CPT::nn:  return 4;
+  case CPT::cnn: return 5;
+  default: cedr_throw_if(true, "Invalid problem type."); return -1;
+  }
+}
+
+int QLTHip::MetaData::get_problem_type_l2r_bulk_size (const int& mask) {
+  if (mask & ProblemType::nonnegative) return (mask & ProblemType::conserve) ? 2 : 1;
+  return (mask & ProblemType::conserve) ? 4 : 3;
+}
+
+int QLTHip::MetaData::get_problem_type_r2l_bulk_size (const int& mask) {
+  return (mask & ProblemType::shapepreserve) ? 1 : 3;
+}
+
+void QLTHip::MetaData::init (const std::vector<int>& t2p) {
+  const Int ntracers = static_cast<Int>(t2p.size());
+  trcr2prob.assign(t2p.begin(), t2p.end());
+  bidx2trcr.assign(ntracers, -1);
+  trcr2bidx.assign(ntracers, -1);
+  trcr2bl2r.assign(ntracers, -1);
+  trcr2br2l.assign(ntracers, -1);
+  prob2trcrptr[0] = 0;
+  prob2bl2r[0] = 1;  // rhom is field 0
+  prob2br2l[0] = 0;
+  for (Int pi = 0; pi < nprobtypes; ++pi) {
+    const Int pt = get_problem_type(pi);
+    const Int l2rsz = get_problem_type_l2r_bulk_size(pt), r2lsz = get_problem_type_r2l_bulk_size(pt);
+    Int cnt = 0;
+    for (Int ti = 0; ti < ntracers; ++ti) {
+      if (trcr2prob[ti] != pt) continue;
+      trcr2bl2r[ti] = prob2bl2r[pi] + cnt*l2rsz;
+      trcr2br2l[ti] = prob2br2l[pi] + cnt*r2lsz;
+      bidx2trcr[prob2trcrptr[pi] + cnt] = ti;
+      ++cnt;
+    }
+    prob2trcrptr[pi+1] = prob2trcrptr[pi] + cnt;
+    prob2bl2r[pi+1] = prob2bl2r[pi] + cnt*l2rsz;
+    prob2br2l[pi+1] = prob2br2l[pi] + cnt*r2lsz;
+  }
+  for (Int bi = 0; bi < ntracers; ++bi) trcr2bidx[bidx2trcr[bi]] = bi;
+  cedr_assert(prob2trcrptr[nprobtypes] == ntracers);
+}
+
+// ---- construction: reference cedr_qlt.cpp:206-236 ----
+void QLTHip::init (const Parallel::Ptr& p, const Int& ncells, const tree::FlatTree& tree) {
+  p_ = p;
+  ns_ = tree::analyze(p->rank(), ncells, tree);
+  cedr_throw_if(ns_->levels.empty() || ns_->levels[0].nodes.empty(),
+                "QLT does not support 0 cells on a rank.");
+  for (const Int idx : ns_->levels[0].nodes) {
+    const auto n = ns_->node_h(idx);
+    gci2lci_[n->id] = n->offset;
+  }
+  plan::Options popt;
+  if (const char* e = std::getenv("CEDR_HIP_TILE_LEAVES")) popt.max_tile_leaves = std::atoi(e);
+  eng_.reset(new engine::TreeEngine(p, tree, *ns_, popt));
+  mdb_.reset(new std::vector<int>());
+  d_.reset(new Impl());
+  o.l2r_data = o.r2l_data = nullptr;
+  o.stride = eng_->stride();
+  o.trcr2prob = o.trcr2bl2r = o.trcr2br2l = nullptr;
+}
+
+QLTHip::QLTHip (const Parallel::Ptr& p, const Int& ncells, const tree::Node::Ptr& tree,
+                Options options)
+  : CDR(options)
+{
+  init(p, ncells, tree::flatten(tree));
+}
+
+QLTHip::QLTHip (const Parallel::Ptr& p, const Int& ncells, const tree::FlatTree& tree,
+                Options options)
+  : CDR(options)
+{
+  init(p, ncells, tree);
+}
+
+QLTHip::~QLTHip () {}
+
+void QLTHip::print (std::ostream& os) const { ns_->print(os); }
+
+Int QLTHip::nlclcells () const { return static_cast<Int>(ns_->levels[0].nodes.size()); }
+
+void QLTHip::get_owned_glblcells (std::vector<Long>& gcis) const {
+  gcis.resize(ns_->levels[0].nodes.size());
+  for (const Int idx : ns_->levels[0].nodes) {
+    const auto n = ns_->node_h(idx);
+    gcis[n->offset] = n->id;
+  }
+}
+
+Int QLTHip::gci2lci (const Int& gci) const {
+  const auto it = gci2lci_.find(gci);
+  cedr_throw_if(it == gci2lci_.end(), "gci " << gci << " not in gci2lci map.");
+  return it->second;
+}
+
+// ---- tracer declaration: reference cedr_qlt.cpp:276-325 ----
+void QLTHip::declare_tracer (int problem_type, const Int& rhomidx) {
+  cedr_throw_if( ! mdb_, "end_tracer_declarations was already called; "
+                 "it is an error to call declare_tracer now.");
+  cedr_throw_if(rhomidx > 0, "rhomidx > 0 is not supported yet.");
+  problem_type = MetaData::get_problem_type(MetaData::get_problem_type_idx(problem_type));
+  mdb_->push_back(problem_type);
+}
+
+void QLTHip::end_tracer_declarations () {
+  cedr_throw_if( ! mdb_, "end_tracer_declarations was already called.");
+  md_.init(*mdb_);
+  mdb_.reset();
+  const Int nt = get_num_tracers();
+  Impl& d = *d_;
+  d.trcr2prob.upload(md_.trcr2prob);
+  d.trcr2bl2r.upload(md_.trcr2bl2r);
+  d.trcr2br2l.upload(md_.trcr2br2l);
+  std::vector<Int> bp(nt), bl(nt), br(nt);
+  for (Int bi = 0; bi < nt; ++bi) {
+    const Int ti = md_.bidx2trcr[bi];
+    bp[bi] = md_.trcr2prob[ti]; bl[bi] = md_.trcr2bl2r[ti]; br[bi] = md_.trcr2br2l[ti];
+  }
+  d.bidx_prob.upload(bp);
+  d.bidx_l2r.upload(bl);
+  d.bidx_r2l.upload(br);
+  // Combine rule of every l2r field, cedr_qlt.cpp:375-383: sums, except that a
+  // consistent-only tracer carries min(q_min) and max(q_max).
+  const Int l2rndps = md_.prob2bl2r[MetaData::nprobtypes];
+  std::vector<uint8_t> op(l2rndps, 0);
+  for (Int ti = 0; ti < nt; ++ti) {
+    const Int pt = md_.trcr2prob[ti];
+    if ((pt & ProblemType::consistent) && ! (pt & ProblemType::shapepreserve)) {
+      op[md_.trcr2bl2r[ti]] = 1;
+      op[md_.trcr2bl2r[ti] + 2] = 2;
+    }
+  }
+  d.l2r_op.upload(op);
+  o.trcr2prob = d.trcr2prob.data();
+  o.trcr2bl2r = d.trcr2bl2r.data();
+  o.trcr2br2l = d.trcr2br2l.data();
+}
+
+// Sizes in Reals. The reference returns ndps * nslots (cedr_qlt.cpp:293-298);
+// this build needs ndps * stride, which is smaller except for degenerate
+// trees, so the reference's figure is reported whenever it suffices.
+void QLTHip::get_buffers_sizes (size_t& buf1, size_t& buf2) {
+  cedr_throw_if(mdb_ != nullptr, "call end_tracer_declarations first");
+  const size_t need = static_cast<size_t>(eng_->stride());
+  const size_t nslots = std::max(need, static_cast<size_t>(ns_->nslots));
+  buf1 = md_.prob2bl2r[MetaData::nprobtypes]*nslots;
+  buf2 = md_.prob2br2l[MetaData::nprobtypes]*nslots;
+}
+
+void QLTHip::set_buffers (Real* buf1, Real* buf2) {
+  d_->l2r = buf1;
+  d_->r2l = buf2;
+  d_->inited = true;
+}
+
+void QLTHip::finish_setup () {
+  Impl& d = *d_;
+  if ( ! d.inited) {
+    size_t l2r_sz, r2l_sz;
+    get_buffers_sizes(l2r_sz, r2l_sz);
+    d.l2r_own.alloc_zero(l2r_sz);
+    d.r2l_own.alloc_zero(r2l_sz);
+    d.l2r = d.l2r_own.data();
+    d.r2l = d.r2l_own.data();
+    d.inited = true;
+  }
+  o.l2r_data = d.l2r;
+  o.r2l_data = d.r2l;
+  d.lay.nt = get_num_tracers();
+  d.lay.l2rndps = md_.prob2bl2r[MetaData::nprobtypes];
+  d.lay.r2lndps = md_.prob2br2l[MetaData::nprobtypes];
+  d.lay.prefer_mass_con = options_.prefer_numerical_mass_conservation_to_numerical_bounds;
+  d.lay.stride = eng_->stride();
+  d.lay.bidx_prob = d.bidx_prob.data();
+  d.lay.bidx_l2r = d.bidx_l2r.data();
+  d.lay.bidx_r2l = d.bidx_r2l.data();
+  d.lay.l2r_op = d.l2r_op.data();
+}
+
+int QLTHip::get_problem_type (const Int& tracer_idx) const {
+  cedr_throw_if(tracer_idx < 0 || tracer_idx >= static_cast<Int>(md_.trcr2prob.size()),
+                "tracer_idx is out of bounds: " << tracer_idx);
+  return md_.trcr2prob[tracer_idx];
+}
+
+Int QLTHip::get_num_tracers () const { return static_cast<Int>(md_.trcr2prob.size()); }
+
+const QLTHip::DeviceOp& QLTHip::get_device_op () { return o; }
+
+void QLTHip::set_stream (hipStream_t stream) { d_->stream = stream; }
+
+void QLTHip::set_rhom_bulk (const Real* rhom) {
+  cedr_throw_if( ! o.l2r_data, "finish_setup was not called");
+  cedr_k_check(cedr_hip_qlt_set_rhom(o.stride, nlclcells(), rhom, o.l2r_data, d_->stream));
+}
+
+void QLTHip::set_Qm_bulk (const Real* Qm, const Real* Qm_min, const Real* Qm_max,
+                          const Real* Qm_prev) {
+  cedr_throw_if( ! o.l2r_data, "finish_setup was not called");
+  cedr_k_check(cedr_hip_qlt_set_Qm(get_num_tracers(), o.trcr2prob, o.trcr2bl2r, o.stride,
+                                   nlclcells(), Qm, Qm_min, Qm_max, Qm_prev, o.l2r_data,
+                                   d_->stream));
+}
+
+void QLTHip::get_Qm_bulk (Real* Qm_out) const {
+  cedr_throw_if( ! o.r2l_data, "finish_setup was not called");
+  cedr_k_check(cedr_hip_qlt_get_Qm(get_num_tracers(), o.trcr2br2l, o.stride, nlclcells(),
+                                   o.r2l_data, Qm_out, d_->stream));
+}
+
+// Leaves->root over the local stages, one all-gather, the replicated top
+// stages, root_compute, then the same stages root->leaves.
+void QLTHip::run () {
+  Impl& d = *d_;
+  cedr_throw_if( ! d.inited || ! o.l2r_data, "finish_setup was not called");
+  hipStream_t s = d.stream;
+  eng_->up(d.lay.l2rndps, d.lay.l2r_op, d.l2r, false, s);
+  cedr_k_check(cedr_hip_qlt_root(&d.lay, eng_->get_plan().root_slot, d.l2r, d.r2l, s));
+  const auto& top = eng_->top_stages();
+  for (size_t i = top.size(); i > 0; --i)
+    cedr_k_check(cedr_hip_qlt_down(&d.lay, &top[i-1]->h, d.l2r, d.r2l, s));
+  eng_->top_to_local(d.lay.r2lndps, d.r2l, s);
+  const auto& loc = eng_->local_stages();
+  for (size_t i = loc.size(); i > 0; --i)
+    cedr_k_check(cedr_hip_qlt_down(&d.lay, &loc[i-1]->h, d.l2r, d.r2l, s));
+}
+
+}  // namespace qlt
+}  // namespace cedr

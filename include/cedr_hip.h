@@ -1,0 +1,268 @@
+/* cedr_hip.h -- C ABI of the MI355X (gfx950) CEDR limiter library, libcedr_hip.so.
+ *
+ * Two layers, both plain C (pointers, sizes, opaque handles; no C++ or torch
+ * types cross this boundary; nothing throws across it):
+ *
+ *  (K) kernel level  cedr_hip_*  : the hand-written HIP kernels, one entry point
+ *      per device lambda of the reference. These are what a
+ *      `QLT<ExeSpace>` / `CAAS<ExeSpace>` specialisation inside the reference
+ *      would call instead of its Kokkos::parallel_for bodies. All pointers are
+ *      DEVICE pointers unless a parameter says "host". Every call enqueues work
+ *      on `stream` and returns immediately.
+ *
+ *  (O) object level  cedr_*      : the cedr::CDR plugin protocol
+ *      (reference cedr/cedr_cdr.hpp:16-112) flattened to C for non-C++ callers
+ *      (E3SM's Fortran side binds COMPOSE this way) and for the Python tests.
+ *      The C++ classes with the reference's own names live in
+ *      compose_amd/csrc/cedr_{cdr,qlt,caas,bfb_tree_allreduce,tree,mpi}.hpp.
+ *
+ * Return value: 0 on success; a positive hipError_t from layer K; -1 from layer
+ * O with the text available from cedr_last_error().
+ */
+#ifndef CEDR_HIP_H
+#define CEDR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* cedr_stream_t; /* == hipStream_t */
+
+/* ------------------------------------------------------------------ layer K */
+
+/* One tile: a subtree one workgroup sweeps in LDS (see DESIGN.md "Tiles"). */
+typedef struct {
+  int32_t in0, nleaf, out, nint, kids_off, lvl_off, nlvl, pad;
+} cedr_hip_tile;
+
+/* One stage: tiles that are swept by one kernel launch. Arrays are device
+ * memory. kids: 2 local node ids per internal node; lvlptr: per tile nlvl+1
+ * offsets. */
+typedef struct {
+  int32_t ntiles, max_nodes, max_nint, pad;
+  const cedr_hip_tile* tiles;
+  const uint16_t* kids;
+  const int32_t* lvlptr;
+} cedr_hip_stage;
+
+/* QLT record layout. Bulk data are stored field-major:
+ *   l2r[field*stride + slot], r2l[field*stride + slot]
+ * where `field` is the reference's index inside a slot record
+ * (cedr_qlt_inl.hpp:14-58: 0 = rhom, trcr2bl2r(ti)+{0,1,2,3} ...). The
+ * per-tracer arrays are indexed by BULK index (reference bidx2trcr order). */
+typedef struct {
+  int32_t nt, l2rndps, r2lndps, prefer_mass_con;
+  int64_t stride;
+  const int32_t* bidx_prob;  /* [nt] canonical problem type            */
+  const int32_t* bidx_l2r;   /* [nt] first l2r field of the tracer     */
+  const int32_t* bidx_r2l;   /* [nt] first r2l field of the tracer     */
+  const uint8_t* l2r_op;     /* [l2rndps] 0 sum, 1 min, 2 max per field */
+} cedr_hip_qlt_layout;
+
+/* Leaves->root sweep of `nfields` independent fields over one stage: every
+ * internal node gets op(kid0, kid1); only tile roots are written back.
+ * Replaces QLT::l2r_combine_kid_data (cedr_qlt.cpp:339-430) for all levels
+ * inside the stage's tiles, and the combine loop of
+ * BfbTreeAllReducer::allreduce (cedr_bfb_tree_allreduce.cpp:114-124) when
+ * zero_init != 0 (then a node is 0 + kid0 + kid1, as the reference computes). */
+int cedr_hip_tree_up(const cedr_hip_stage* stage, int32_t nfields, const uint8_t* op,
+                     int64_t stride, double* data, int zero_init, cedr_stream_t stream);
+
+/* Root->leaves sweep over one stage: re-forms the tile's node sums in LDS,
+ * takes the tile root's assigned mass from r2l, solves every node problem
+ * (cedr_qlt_inl.hpp:120-203 via cedr_qlt.cpp:525-604) and writes the inputs'
+ * masses. Replaces QLT::r2l_solve_qp for all levels inside the stage. */
+int cedr_hip_qlt_down(const cedr_hip_qlt_layout* lay, const cedr_hip_stage* stage,
+                      double* l2r, double* r2l, cedr_stream_t stream);
+
+/* QLT::root_compute (cedr_qlt.cpp:441-476). */
+int cedr_hip_qlt_root(const cedr_hip_qlt_layout* lay, int32_t root_slot,
+                      const double* l2r, double* r2l, cedr_stream_t stream);
+
+/* Boundary exchange helpers (replace the per-level MPI messages of
+ * cedr_qlt.cpp:327-337,432-439,478-488,606-613):
+ * gather : out[j*nfields + f] = data[f*stride + slots[j]], j < n
+ * scatter: data[f*stride + slots[q]] = in[q*nfields + f] for slots[q] >= 0, q < n
+ * copy   : data[f*stride + dst[j]] = data[f*stride + src[j]], j < n            */
+int cedr_hip_gather_slots(const double* data, int64_t stride, int32_t nfields,
+                          const int32_t* slots, int32_t n, double* out, cedr_stream_t stream);
+int cedr_hip_scatter_slots(double* data, int64_t stride, int32_t nfields,
+                           const int32_t* slots, int32_t n, const double* in, cedr_stream_t stream);
+/* scatter with a field-major source: data[f*stride + slots[q]] = in[f*n + q] */
+int cedr_hip_scatter_slots_fm(double* data, int64_t stride, int32_t nfields,
+                              const int32_t* slots, int32_t n, const double* in,
+                              cedr_stream_t stream);
+int cedr_hip_copy_slots(double* data, int64_t stride, int32_t nfields, const int32_t* src,
+                        const int32_t* dst, int32_t n, cedr_stream_t stream);
+
+/* Bulk forms of QLT::DeviceOp::set_rhom / set_Qm / get_Qm
+ * (cedr_qlt_inl.hpp:14-66) for n local cells; caller arrays are [tracer][cell]
+ * in the CALLER's tracer order; trcr_* arrays are indexed by caller tracer. */
+int cedr_hip_qlt_set_rhom(int64_t stride, int32_t n, const double* rhom, double* l2r,
+                          cedr_stream_t stream);
+int cedr_hip_qlt_set_Qm(int32_t nt, const int32_t* trcr_prob, const int32_t* trcr_l2r,
+                        int64_t stride, int32_t n, const double* Qm, const double* Qm_min,
+                        const double* Qm_max, const double* Qm_prev, double* l2r,
+                        cedr_stream_t stream);
+int cedr_hip_qlt_get_Qm(int32_t nt, const int32_t* trcr_r2l, int64_t stride, int32_t n,
+                        const double* r2l, double* Qm_out, cedr_stream_t stream);
+
+/* CAAS::reduce_locally (cedr_caas.cpp:129-201), own-reducer branch, fused:
+ * clips Qm (read from qm_src, or from d if NULL; written to d), and forms the
+ * four per-tracer sums. Stage 1 writes per-chunk partials, stage 2
+ * (cedr_hip_caas_sum_partials) adds them in fixed order into send[4*nt] =
+ * [sum clip | sum Qm_prev or Qm | sum Qm_min | sum Qm_max].
+ * d is the reference's SoA buffer (cedr_caas_inl.hpp:22-34).
+ * partials must hold 4*nt*cedr_hip_caas_nchunks(n) doubles. */
+int32_t cedr_hip_caas_nchunks(int32_t n);
+int cedr_hip_caas_reduce_local(const int32_t* probs, int32_t nt, int32_t n, int need_conserve,
+                               double* d, const double* qm_src, double* partials,
+                               cedr_stream_t stream);
+int cedr_hip_caas_sum_partials(int32_t nt, int32_t n, const double* partials, double* send,
+                               cedr_stream_t stream);
+/* User-reducer branch (cedr_caas.cpp:137-168): per-group partial sums in the
+ * reference's send layout, send[nlclaccum*f + bi]. */
+int cedr_hip_caas_reduce_local_accum(const int32_t* probs, int32_t nt, int32_t n,
+                                     int need_conserve, int32_t n_accum_in_place, double* d,
+                                     double* send, cedr_stream_t stream);
+/* CAAS::finish_locally (cedr_caas.cpp:211-253). recv[4*nt]. */
+int cedr_hip_caas_finish_local(int32_t nt, int32_t n, double* d, const double* recv,
+                               cedr_stream_t stream);
+/* Bulk CAAS::DeviceOp::set_Qm / get_Qm (cedr_caas_inl.hpp:22-42) are plain
+ * copies into/out of d because the layouts coincide: use hipMemcpyAsync. */
+
+/* ------------------------------------------------------------------ layer O */
+/* Handles are opaque. Creation functions return NULL on failure. */
+const char* cedr_last_error(void);
+
+/* -- cedr::mpi::Parallel (reference cedr/cedr_mpi.hpp:17-37) ---------------- */
+void* cedr_parallel_create_self(void);
+/* One process per GPU over RCCL; unique_id from cedr_rccl_get_unique_id on one
+ * rank, distributed by the launcher. */
+int cedr_rccl_get_unique_id(void* unique_id_128B);
+void* cedr_parallel_create_rccl(const void* unique_id_128B, int rank, int size);
+/* Host-application transport (e.g. GPU-aware MPI). Buffers are device memory. */
+typedef int (*cedr_allgather_fn)(void* user, const double* send, double* recv, size_t count,
+                                 cedr_stream_t stream);
+typedef int (*cedr_allreduce_sum_fn)(void* user, const double* send, double* recv, size_t count,
+                                     cedr_stream_t stream);
+void* cedr_parallel_create_callbacks(int rank, int size, cedr_allgather_fn ag,
+                                     cedr_allreduce_sum_fn ar, void* user);
+int cedr_parallel_rank(void* p);
+int cedr_parallel_size(void* p);
+void cedr_parallel_free(void* p);
+
+/* -- caller tree (reference cedr/cedr_tree_caller.hpp:12-30) ---------------- */
+/* Binary tree from arrays: kid0/kid1 = -1 at leaves; rank and cellidx are read
+ * at leaves (rank >= 0 at an internal node pins that node's rank). */
+void* cedr_tree_create(int nnodes, int root, const int* kid0, const int* kid1, const int* rank,
+                       const long* cellidx);
+/* tree::make_tree_over_1d_mesh / oned::make_tree (cedr_tree.cpp:350-420). */
+void* cedr_tree_make_1d(int ncells, int nranks, int pseudorandom, int imbalanced);
+void cedr_tree_free(void* tree);
+
+/* -- tree::analyze (reference cedr/cedr_tree.cpp:215-231), host only -------- */
+void* cedr_tree_analyze(void* tree, int ncells, int my_rank);
+void cedr_ns_free(void* ns);
+int cedr_ns_nslots(void* ns);
+int cedr_ns_nnode(void* ns);
+int cedr_ns_nlevels(void* ns);
+int cedr_ns_level_size(void* ns, int il);
+int cedr_ns_level_nme(void* ns, int il);
+int cedr_ns_level_nkids(void* ns, int il);
+void cedr_ns_nodes(void* ns, int* out_nnode_x7); /* rank,id,parent,nkids,kid0,kid1,offset */
+void cedr_ns_level_nodes(void* ns, int il, int* out);
+void cedr_ns_level_msgs(void* ns, int il, int which /*0 me, 1 kids*/, int* out_n_x3);
+int cedr_ns_check_comm(void* ns);
+
+/* -- cedr::qlt::QLT (reference cedr/cedr_qlt.hpp:129-197) ------------------- */
+void* cedr_qlt_create(void* parallel, int ncells, void* tree, int prefer_mass_con);
+void cedr_qlt_free(void* qlt);
+int cedr_qlt_declare_tracer(void* qlt, int problem_type, int rhomidx);
+int cedr_qlt_end_tracer_declarations(void* qlt);
+int cedr_qlt_get_buffers_sizes(void* qlt, size_t* buf1, size_t* buf2); /* in doubles */
+int cedr_qlt_set_buffers(void* qlt, double* buf1, double* buf2);       /* device memory */
+int cedr_qlt_finish_setup(void* qlt);
+int cedr_qlt_get_problem_type(void* qlt, int tracer_idx); /* < 0 on error */
+int cedr_qlt_get_num_tracers(void* qlt);
+int cedr_qlt_nlclcells(void* qlt);
+int cedr_qlt_get_owned_glblcells(void* qlt, long* gcis);
+int cedr_qlt_gci2lci(void* qlt, int gci); /* < 0 on error */
+int cedr_qlt_run(void* qlt);
+int cedr_qlt_set_stream(void* qlt, cedr_stream_t stream);
+/* DeviceOp for C callers: the values a device kernel needs to do set/get itself. */
+typedef struct {
+  double* l2r_data; double* r2l_data; int64_t stride;
+  const int* trcr2prob; const int* trcr2bl2r; const int* trcr2br2l;
+} cedr_qlt_device_op;
+int cedr_qlt_get_device_op(void* qlt, cedr_qlt_device_op* out);
+/* Bulk set_rhom / set_Qm / get_Qm over all local cells; device arrays
+ * [tracer][cell] in caller tracer order. */
+int cedr_qlt_set_rhom_bulk(void* qlt, const double* rhom);
+int cedr_qlt_set_Qm_bulk(void* qlt, const double* Qm, const double* Qm_min,
+                         const double* Qm_max, const double* Qm_prev);
+int cedr_qlt_get_Qm_bulk(void* qlt, double* Qm_out);
+/* QLT::MetaData (cedr_qlt.hpp:46-109): five arrays of nt ints, three of 7. */
+int cedr_qlt_metadata(void* qlt, int* trcr2prob, int* bidx2trcr, int* trcr2bidx,
+                      int* trcr2bl2r, int* trcr2br2l, int* prob2trcrptr, int* prob2bl2r,
+                      int* prob2br2l);
+void* cedr_qlt_nodesets(void* qlt); /* borrowed NodeSets handle for cedr_ns_* */
+/* Execution plan (host copy), for inspection and for the CPU multi-rank tests.
+ * cedr_plan_create builds one without touching a GPU; cedr_qlt_plan borrows
+ * the one a QLT runs (valid while the QLT lives; do not free it).
+ * summary[8] = {nlcl, nslots, #local stages, #top stages, root_slot, nb_max,
+ *               #my boundary roots, stride}. */
+void* cedr_plan_create(void* tree, int ncells, int my_rank, int nranks, int max_tile_leaves);
+void cedr_plan_free(void* plan);
+void* cedr_qlt_plan(void* qlt);
+int cedr_plan_summary(void* plan, int64_t* summary8);
+/* sizes[4] = {ntiles, max_nodes, #internal nodes, #lvlptr entries} */
+int cedr_plan_stage_sizes(void* plan, int top, int idx, int* sizes4);
+int cedr_plan_stage(void* plan, int top, int idx, int* tiles_x8, uint16_t* kids, int* lvlptr);
+/* my_root_slots[#my roots], my_top_slots[#my roots], gather_slots[nranks*nb_max] */
+int cedr_plan_exchange(void* plan, int* my_root_slots, int* my_top_slots, int* gather_slots);
+
+/* -- cedr::caas::CAAS (reference cedr/cedr_caas.hpp:51-96) ------------------ */
+/* UserAllReducer (cedr_caas.hpp:27-49) as a callback; NULL = own all-reduce. */
+typedef int (*cedr_user_allreduce_fn)(void* user, double* sendbuf, double* rcvbuf, int nlocal,
+                                      int nfld);
+void* cedr_caas_create(void* parallel, int nlclcells, cedr_user_allreduce_fn reducer,
+                       int n_accum_in_place, void* user);
+void cedr_caas_free(void* caas);
+int cedr_caas_declare_tracer(void* caas, int problem_type, int rhomidx);
+int cedr_caas_end_tracer_declarations(void* caas);
+int cedr_caas_get_buffers_sizes(void* caas, size_t* buf1, size_t* buf2);
+int cedr_caas_set_buffers(void* caas, double* buf1, double* buf2);
+int cedr_caas_finish_setup(void* caas);
+int cedr_caas_get_problem_type(void* caas, int tracer_idx);
+int cedr_caas_get_num_tracers(void* caas);
+int cedr_caas_run(void* caas);
+int cedr_caas_set_stream(void* caas, cedr_stream_t stream);
+int cedr_caas_set_Qm_source(void* caas, const double* qm_src);
+typedef struct { double* d; int nlclcells; int nt; int need_conserve; } cedr_caas_device_op;
+int cedr_caas_get_device_op(void* caas, cedr_caas_device_op* out);
+int cedr_caas_get_recv(void* caas, const double** recv_dev);
+
+/* -- cedr::BfbTreeAllReducer (reference cedr/cedr_bfb_tree_allreduce.hpp) ---- */
+void* cedr_bfb_create(void* parallel, void* tree, int nleaf, int nfield);
+void cedr_bfb_free(void* bfb);
+int cedr_bfb_nlocal(void* bfb);
+int cedr_bfb_allreduce(void* bfb, const double* send, double* recv, int transpose);
+
+/* -- device memory helpers for hosts without their own HIP bindings ---------- */
+int cedr_device_count(void);
+void* cedr_malloc(size_t bytes);
+void cedr_free(void* p);
+int cedr_memcpy_h2d(void* dst, const void* src, size_t bytes);
+int cedr_memcpy_d2h(void* dst, const void* src, size_t bytes);
+int cedr_memcpy_d2d_async(void* dst, const void* src, size_t bytes, cedr_stream_t stream);
+int cedr_device_synchronize(void);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* CEDR_HIP_H */

@@ -1,0 +1,84 @@
+"""GPU parity of CAAS against the CPU oracle. The oracle sums cells serially
+(Kokkos-Serial order); the HIP path sums in a fixed tree order, so sums agree to
+rounding and the reconstructed masses to 1e-13 relative (north star tolerance)."""
+import numpy as np
+import pytest
+
+import common
+import randomized as R
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-13
+
+
+def _rel(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+# caas::test::unittest (cedr_caas.cpp:381-393): nlclcells in {1,2,4,11}, own reducer or
+# not, external memory or not; plus sizes that span several chunks, odd and even.
+@pytest.mark.parametrize("ncells", [1, 2, 4, 11, 1000, 4097, 20000])
+@pytest.mark.parametrize("external_memory", [False, True])
+def test_caas_harness(gpu, oracle, ncells, external_memory):
+    ca = gpu
+    trs = R.caas_tracers(R.tracers_vector())
+    v = R.make_values(trs, ncells, seed=300 + ncells)
+    types = [t.problem_type for t in trs]
+    want, _ = common.run_oracle_caas(oracle, [ncells], types, v)
+    got = common.run_hip_caas(ca, ncells, types, v, external_memory)
+    assert _rel(got, want) <= TOL
+    nerr, msgs = R.check(trs, v, got)
+    assert nerr == 0, msgs[:5]
+    # perturbation 0 must come back exactly
+    for t in trs:
+        if t.no_change_should_hold:
+            assert np.array_equal(got[t.idx], v.Qm_prev[t.idx])
+
+
+@pytest.mark.parametrize("ncells,accum", [(12, 3), (12, 2), (11, 1), (3000, 3)])
+def test_caas_user_reducer(gpu, oracle, ncells, accum):
+    """UserAllReducer path (cedr_caas.cpp:137-168,263-266) with the reference test's
+    reducer (cedr_caas.cpp:304-321) run on the host through device copies."""
+    ca = gpu
+    trs = R.caas_tracers(R.tracers_vector())
+    v = R.make_values(trs, ncells, seed=77)
+    types = [t.problem_type for t in trs]
+    L = ca.lib()
+
+    def reducer(send, recv, nlocal, nfld):
+        s = np.empty(nlocal * nfld)
+        L.cedr_memcpy_d2h(s.ctypes.data, send, s.nbytes)
+        r = np.empty(nfld)
+        for k in range(nfld):
+            acc = s[nlocal * k]
+            for i in range(1, nlocal):
+                acc += s[nlocal * k + i]
+            r[k] = acc
+        L.cedr_memcpy_h2d(recv, r.ctypes.data, r.nbytes)
+        return 0
+
+    want, _ = common.run_oracle_caas(oracle, [ncells], types, v, accum=accum)
+    got = common.run_hip_caas(ca, ncells, types, v, user_reducer=reducer, accum=accum)
+    assert np.array_equal(got, want)  # same summation order as the oracle => bit for bit
+
+
+def test_caas_qm_source_matches_in_place(gpu):
+    ca = gpu
+    trs = [R.Tracer(i, 7, 1) for i in range(5)]
+    v = R.make_values(trs, 8192 + 6, seed=3)
+    a = common.run_hip_caas(ca, v.ncells, [7] * 5, v)
+    b = common.run_hip_caas(ca, v.ncells, [7] * 5, v, qm_source=True)
+    assert np.array_equal(a, b)
+
+
+def test_caas_errors(gpu):
+    ca = gpu
+    with pytest.raises(ca.CedrError):
+        ca.CAAS(ca.Parallel.self_(), 0)  # cedr_caas.cpp:46
+    c = ca.CAAS(ca.Parallel.self_(), 4)
+    with pytest.raises(ca.CedrError):
+        c.declare_tracer(4, 0)  # !shapepreserve, cedr_caas.cpp:52-53
+    with pytest.raises(ca.CedrError):
+        c.declare_tracer(7, 1)  # rhomidx > 0
+    with pytest.raises(ca.CedrError):
+        c.end_tracer_declarations()  # 0 tracers, cedr_caas.cpp:62
