@@ -1,0 +1,283 @@
+#!/usr/bin/env python3
+"""bench.py -- cell-tracer-updates/s of the CEDR limiter hot path (QLT + CAAS) on MI355X.
+
+One "step" = one QLT::run() plus one CAAS::run() over the same synthetic
+(ncells x ntracers) problem, all tracers conserve|shapepreserve|consistent, inputs
+resident in HBM before the timed region. value = cell-tracer
+updates by both algorithms per second = 2*ncells*ntracers / time per step.
+
+N GPUs: `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`;
+the global problem is sharded contiguously over ranks (strong scaling). The data
+path uses the library's own RCCL communicator (one all-gather per QLT run, one
+all-reduce per CAAS run); torch.distributed (gloo) is only the control plane
+(unique-id broadcast, barriers, max over ranks).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured copy)
+CST = 7
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--ncells", type=int, default=1500000)
+    ap.add_argument("--ntracers", type=int, default=40)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-cells", type=int, default=375000,
+                    help="cells of the bounded CPU-baseline sample (same tracer count)")
+    ap.add_argument("--check", action="store_true", help="verify properties of the results")
+    return ap.parse_args()
+
+
+def gen_inputs(torch, n, nt, seed, device):
+    """SURVEY.md 8(d) synthetic inputs for one shard: arrays [tracer][cell] on the device."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    f64 = torch.float64
+    rhom = 0.5 * (1 + torch.rand(n, generator=g, device=device, dtype=f64))
+    q_min = -0.75 + torch.rand(nt, n, generator=g, device=device, dtype=f64)
+    q_max = q_min + torch.rand(nt, n, generator=g, device=device, dtype=f64)
+    q = q_min + (q_max - q_min) * torch.rand(nt, n, generator=g, device=device, dtype=f64)
+    Qm_min = q_min * rhom
+    Qm_max = q_max * rhom
+    Qm_prev = torch.maximum(Qm_min, torch.minimum(Qm_max, q * rhom))
+    del q_min, q_max, q
+    # perturbation type 1 (cedr_test_randomized.cpp:109-118): permute Qm within the shard
+    Qm = torch.empty_like(Qm_prev)
+    for t in range(nt):
+        Qm[t] = Qm_prev[t][torch.randperm(n, generator=g, device=device)]
+    return rhom, Qm.contiguous(), Qm_min.contiguous(), Qm_max.contiguous(), Qm_prev.contiguous()
+
+
+def cpu_baseline(ncells, nt, nrep_qlt=2, nrep_caas=4):
+    """The oracle (CPU port of the reference algorithm) timed on this host: the
+    reported CPU baseline, never the thing measured as `value`."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as o
+    rng = np.random.default_rng(12345)
+    rhom = 0.5 * (1 + rng.random(ncells))
+    q_min = -0.75 + rng.random((nt, ncells))
+    q_max = q_min + rng.random((nt, ncells))
+    q = q_min + (q_max - q_min) * rng.random((nt, ncells))
+    Qm_min, Qm_max = q_min * rhom, q_max * rhom
+    Qm_prev = np.maximum(Qm_min, np.minimum(Qm_max, q * rhom))
+    del q_min, q_max, q
+    Qm = np.empty_like(Qm_prev)
+    for t in range(nt):
+        Qm[t] = Qm_prev[t][rng.permutation(ncells)]
+    nthr = min(o.lib().or_max_threads(), 16)  # the GPU box share of host cores for one GPU
+    tree = o.Tree.make_1d(ncells)
+    qlt = o.OracleQLT(tree, ncells)
+    qlt.declare([CST] * nt)
+    qlt.set(0, rhom, Qm, Qm_min, Qm_max, Qm_prev)
+    caas = o.OracleCAAS([ncells], [CST] * nt)
+    caas.set(0, rhom, Qm, Qm_min, Qm_max, Qm_prev)
+    res = {}
+    for label, threads in (("1", 1), ("all", nthr)):
+        qlt.set_threads(threads)
+        caas.set_threads(threads)
+        qlt.run()  # warm-up
+        tq = qlt.time_run(nrep_qlt) / nrep_qlt
+        tc = caas.time_run(Qm, nrep_caas) / nrep_caas
+        res[label] = dict(threads=threads, qlt_s=tq, caas_s=tc,
+                          value=2.0 * ncells * nt / (tq + tc),
+                          qlt_updates_per_s=ncells * nt / tq, caas_updates_per_s=ncells * nt / tc)
+        if nthr == 1:
+            res["all"] = res["1"]
+            break
+    return res, nthr
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+    import compose_amd as ca
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d`"
+                             % (a.gpus, a.gpus))
+        raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, a.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    torch.zeros(1, device=device)  # initialise the HIP context before the library is used
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        uid = [ca.Parallel.rccl_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        par = ca.Parallel.rccl(uid[0], rank, world)
+    else:
+        par = ca.Parallel.self_()
+
+    ncells, nt = a.ncells, a.ntracers
+    tree = ca.Tree.make_1d(ncells, world, False, False)  # contiguous ownership, balanced
+    qlt = ca.QLT(par, ncells, tree)
+    for _ in range(nt):
+        qlt.declare_tracer(CST, 0)
+    qlt.end_tracer_declarations()
+    qlt.finish_setup()
+    n = qlt.nlclcells()
+    caas = ca.CAAS(par, n)
+    for _ in range(nt):
+        caas.declare_tracer(CST, 0)
+    caas.end_tracer_declarations()
+    caas.finish_setup()
+
+    rhom, Qm, Qm_min, Qm_max, Qm_prev = gen_inputs(torch, n, nt, 0x5EED0000 + 1000 * 2 + rank, device)
+    qlt.set_rhom(rhom)
+    qlt.set_Qm(Qm, Qm_min, Qm_max, Qm_prev)
+    caas.set_rhom(rhom)
+    caas.set_Qm(Qm, Qm_min, Qm_max, Qm_prev)
+    caas.set_Qm_source(Qm)  # every run() reads the pristine Qm: identical work each step
+    torch.cuda.synchronize()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    def step():
+        qlt.run()
+        caas.run()
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    t1 = time.perf_counter()
+    dt = t1 - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt[0])
+    ms_per_step = 1e3 * dt / a.steps
+    value = 2.0 * ncells * nt / (dt / a.steps)
+
+    # Split of the step between the two algorithms (same loop shape, timed apart).
+    def timed(fn):
+        torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
+        s = time.perf_counter()
+        for _ in range(a.steps):
+            fn()
+        torch.cuda.synchronize(); barrier()
+        e = time.perf_counter() - s
+        if world > 1:
+            tt = torch.tensor([e], dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            e = float(tt[0])
+        return e / a.steps
+    t_qlt = timed(qlt.run)
+    t_caas = timed(caas.run)
+
+    # Roofline leg: HIP events around every kernel launch, on the launch stream,
+    # over `steps` more steps of the same loop.
+    ca.profile_start()
+    for _ in range(a.steps):
+        step()
+    recs = ca.profile_stop()
+    per = {}
+    for name, aux, ms in recs:
+        k = (name, aux)
+        c = per.setdefault(k, [0, 0.0])
+        c[0] += 1
+        c[1] += ms
+    # Algorithmic HBM bytes per launch (DESIGN.md "Roofline accounting"), cst tracers:
+    #   tree_up stage 1  : reads the 4 l2r fields of every cell-tracer + rhom      = n*(32*nt + 8)
+    #   qlt_down stage 1 : reads lo/orig/hi + rhom, writes the cell's new mass     = n*(32*nt + 8)
+    #   caas_reduce      : reads Qm, Qm_min, Qm_max, Qm_prev, writes clipped Qm    = n*nt*40
+    #   caas_finish      : reads Qm and one bound, writes Qm                       = n*nt*24
+    plan = qlt.plan()
+    ntiles1 = len(plan["local"][0]["tiles"]) if plan["local"] else 0
+    alg = {("tree_up_kernel", ntiles1): n * (32.0 * nt + 8), ("qlt_down_kernel", ntiles1): n * (32.0 * nt + 8),
+           ("caas_reduce_kernel", n): n * nt * 40.0, ("caas_finish_kernel", n): n * nt * 24.0}
+    kernels = []
+    for (name, aux), (cnt, tot) in sorted(per.items(), key=lambda kv: -kv[1][1]):
+        avg_ms = tot / cnt
+        e = dict(kernel=name, launch=aux, launches_per_step=cnt / a.steps, avg_ms=avg_ms,
+                 ms_per_step=tot / a.steps)
+        if (name, aux) in alg:
+            gbs = alg[(name, aux)] / (avg_ms * 1e-3) / 1e9
+            e.update(algorithmic_bytes=alg[(name, aux)], achieved_GBs=gbs, frac=gbs / HBM_PEAK_GBS)
+        kernels.append(e)
+    dom = next((k for k in kernels if "achieved_GBs" in k), None)
+    roofline = None
+    if dom:
+        roofline = dict(bound="hbm", kernel=dom["kernel"], achieved=dom["achieved_GBs"],
+                        peak=HBM_PEAK_GBS, unit="GB/s", frac=dom["frac"], traffic=None,
+                        avg_ms=dom["avg_ms"], algorithmic_bytes_per_launch=dom["algorithmic_bytes"])
+
+    ok = None
+    if a.check:
+        out = torch.empty_like(Qm)
+        qlt.get_Qm(out)
+        torch.cuda.synchronize()
+        ok = bool(((out >= Qm_min) & (out <= Qm_max)).all())
+        mass = torch.stack([out.sum(1), Qm_prev.sum(1), Qm_prev.abs().sum(1)])
+        if world > 1:
+            mass = mass.cpu(); dist.all_reduce(mass)
+        ok = ok and bool(((mass[0] - mass[1]).abs() / mass[2]).max() < 1e-13)
+        caas.get_Qm(out)
+        torch.cuda.synchronize()
+        ok = ok and bool(((out >= Qm_min) & (out <= Qm_max)).all())
+
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        try:
+            res, nthr = cpu_baseline(a.cpu_cells, nt)
+            cpu = dict(value=res["all"]["value"], unit="cell-tracer-updates/s", cores=res["all"]["threads"],
+                       kind="port",
+                       sample="oracle (CPU port of the reference algorithm, OpenMP over level nodes / "
+                              "tracers) QLT+CAAS on %d cells x %d cst tracers" % (a.cpu_cells, nt),
+                       host_cores=os.cpu_count(), single_thread=res["1"], all_threads=res["all"])
+        except Exception as e:  # the baseline must never take the bench down
+            cpu = dict(value=None, unit="cell-tracer-updates/s", cores=0, kind="port",
+                       sample="failed: %r" % (e,))
+
+    if rank == 0:
+        line = {
+            "metric": "cell-tracer-updates/sec (QLT+CAAS), 1.5M cells x 40 tracers; % HBM roofline",
+            "value": value, "unit": "cell-tracer-updates/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "QLT::run + CAAS::run, %d cells x %d cst tracers, balanced 1-D tree, "
+                                   "contiguous %d-way sharding" % (ncells, nt, world),
+                       "ncells": ncells, "ntracers": nt, "cells_per_gpu": n},
+            "qlt": {"ms_per_run": 1e3 * t_qlt, "updates_per_s": ncells * nt / t_qlt},
+            "caas": {"ms_per_run": 1e3 * t_caas, "updates_per_s": ncells * nt / t_caas},
+            "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu,
+        }
+        if ok is not None:
+            line["check_ok"] = ok
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -141,6 +141,10 @@ _SIGS = {
     "cedr_hip_caas_reduce_local": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int, _vp, _vp, _vp, _vp]),
     "cedr_hip_caas_sum_partials": (C.c_int, [C.c_int32, C.c_int32, _vp, _vp, _vp]),
     "cedr_hip_caas_finish_local": (C.c_int, [C.c_int32, C.c_int32, _vp, _vp, _vp]),
+    "cedr_hip_profile_start": (None, []),
+    "cedr_hip_profile_stop": (C.c_int, []),
+    "cedr_hip_profile_get": (C.c_int, [C.c_int, _ip, C.POINTER(C.c_int64), C.POINTER(C.c_float)]),
+    "cedr_hip_profile_name": (C.c_char_p, [C.c_int]),
 }
 
 _LIB = None
@@ -570,3 +574,20 @@ class BfbTreeAllReducer:
 
 def synchronize():
     _chk(lib().cedr_device_synchronize(), "synchronize")
+
+
+def profile_start():
+    """Start recording HIP-event timings of every kernel launch of this library."""
+    lib().cedr_hip_profile_start()
+
+
+def profile_stop():
+    """Stop and return a list of (kernel name, aux, milliseconds), one per launch."""
+    L = lib()
+    n = L.cedr_hip_profile_stop()
+    out = []
+    kid, aux, ms = C.c_int(), C.c_int64(), C.c_float()
+    for i in range(n):
+        _chk(L.cedr_hip_profile_get(i, C.byref(kid), C.byref(aux), C.byref(ms)), "profile_get")
+        out.append((L.cedr_hip_profile_name(kid.value).decode(), aux.value, ms.value))
+    return out

@@ -23,7 +23,7 @@ void DeviceStage::upload (const plan::Stage& st) {
   h.ntiles = static_cast<int32_t>(st.tiles.size());
   h.max_nodes = st.max_nodes;
   h.max_nint = st.max_nint;
-  h.pad = 0;
+  h.max_nleaf = st.max_nleaf;
   h.tiles = tiles.data();
   h.kids = kids.data();
   h.lvlptr = lvlptr.data();

@@ -8,348 +8,288 @@
 
 #include <cfloat>
 #include <cstdint>
+#include <vector>
 
 #include "../../include/cedr_hip.h"
+#include "cedr_node_math.hpp"
 
 namespace {
 
 constexpr int kBlock = 256;          // 4 wavefronts
 constexpr int kWave = 64;
-constexpr double kEps = DBL_EPSILON;
+using namespace cedr_dev;
 
-enum : int { CONSERVE = 1, SHAPEPRESERVE = 2, CONSISTENT = 4, NONNEGATIVE = 8 };
+// ------------------------------------------------------------- tile sweeps
+// One workgroup sweeps one tile. It keeps a CHUNK of FT fields (leaves->root)
+// or TT tracers (root->leaves) of that tile in LDS and spreads the (node, field)
+// or (node, tracer) items of every tree level over all 256 threads, so that the
+// small upper levels of a tile still fill the lanes. The workgroup loops over
+// chunks; the next chunk's input loads are in flight in registers while the
+// current one is processed. The tile's kid indices and level offsets are staged
+// in LDS once. LDS rows are pitched (== 1 mod 32 doubles) so that lanes that
+// differ in field/tracer hit different banks.
+constexpr int kNW = kBlock/kWave;
 
-// reference cedr_kokkos.hpp:136-139: comparisons, not fmin/fmax.
-__device__ __forceinline__ double rmin (double a, double b) { return a < b ? a : b; }
-__device__ __forceinline__ double rmax (double a, double b) { return a > b ? a : b; }
-
-// ------------------------------------------------------------------ node math
-// reference cedr_local_inl.hpp:69-165 (solve_1eq_bc_qp_2d) with a = (1, 1).
-// Multiplications and divisions by the constant 1 are dropped: they are exact,
-// so every remaining operation sees the same operands in the same order.
-__device__ void qp_2d (const double w0, const double w1, const double b,
-                       const double lo0, const double lo1, const double hi0, const double hi1,
-                       const double y0, const double y1, double& x0, double& x1,
-                       const bool clip, const bool early_exit_on_tol) {
-  if (early_exit_on_tol) {
-    // calc_r_tol (:14-18) and check_lu (:23-41)
-    double ab = fabs(b);
-    ab = rmax(ab, fabs(y0));
-    ab = rmax(ab, fabs(y1));
-    const double r_tol = 1e1*kEps*fabs(ab);
-    double r = -b;
-    r += lo0; r += lo1;
-    if ( ! (fabs(r) <= r_tol)) {
-      if (r > 0) { x0 = lo0; x1 = lo1; return; }
-      r = -b;
-      r += hi0; r += hi1;
-      if ( ! (fabs(r) <= r_tol) && r < 0) { x0 = hi0; x1 = hi1; return; }
-    }
-  }
-  const double q0 = 1.0/w0, q1 = 1.0/w1;
-  {
-    double qmass = 0;
-    qmass += q0; qmass += q1;
-    double dm = b;
-    dm -= y0; dm -= y1;
-    const double lambda = dm/qmass;
-    x0 = y0 + lambda*q0;
-    if ( ! (x0 < lo0 || x0 > hi0)) {
-      x1 = y1 + lambda*q1;
-      if ( ! (x1 < lo1 || x1 > hi1)) return;
-    }
-  }
-  // Line a'x = b as base + alpha*dir, dir = (-1, 1); intersect the box edges.
-  const double base = 0.5*b;
-  double al[4];
-  al[0] = lo1 - base;      // bottom
-  al[1] = -(hi0 - base);   // right
-  al[2] = hi1 - base;      // top
-  al[3] = -(lo0 - base);   // left
-  double mn = al[0], mx = al[0];
-  int imin = 0, imax = 0;
-#pragma unroll
-  for (int i = 1; i < 4; ++i) {
-    if (al[i] < mn) { mn = al[i]; imin = i; }
-    if (al[i] > mx) { mx = al[i]; imax = i; }
-  }
-  int m0 = -1, m1 = -1;
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-    if (i != imin && i != imax) {
-      if (m0 < 0) m0 = i; else if (m1 < 0) m1 = i;
-    }
-  const double a0 = m0 == 0 ? al[0] : m0 == 1 ? al[1] : m0 == 2 ? al[2] : al[3];
-  const double a1 = m1 == 0 ? al[0] : m1 == 1 ? al[1] : m1 == 2 ? al[2] : al[3];
-  double obj0, obj1;
-  {
-    const double t0 = base - a0, t1 = base + a0;
-    const double d0 = y0 - t0, d1 = y1 - t1;
-    obj0 = 0; obj0 += w0*(d0*d0); obj0 += w1*(d1*d1);
-  }
-  {
-    const double t0 = base - a1, t1 = base + a1;
-    const double d0 = y0 - t0, d1 = y1 - t1;
-    obj1 = 0; obj1 += w0*(d0*d0); obj1 += w1*(d1*d1);
-  }
-  const int ai = obj0 <= obj1 ? m0 : m1;
-  if (ai == 0 || ai == 2) {
-    x1 = ai == 0 ? lo1 : hi1;
-    x0 = b - x1;
-    if (clip) x0 = rmin(hi0, rmax(lo0, x0));
-  } else {
-    x0 = ai == 1 ? hi0 : lo0;
-    x1 = b - x0;
-    if (clip) x1 = rmin(hi1, rmax(lo1, x1));
-  }
+// Stage kid pairs (packed k0 | k1 << 16) and level offsets of a tile in LDS.
+__device__ __forceinline__ void stage_tile_meta (const cedr_hip_stage& st, const cedr_hip_tile& tile,
+                                                 uint32_t* kidsL, int32_t* lvlL) {
+  const uint32_t* __restrict__ kp =
+    reinterpret_cast<const uint32_t*>(st.kids + 2*static_cast<size_t>(tile.kids_off));
+  for (int j = threadIdx.x; j < tile.nint; j += kBlock) kidsL[j] = kp[j];
+  const int32_t* __restrict__ lp = st.lvlptr + tile.lvl_off;
+  for (int j = threadIdx.x; j <= tile.nlvl; j += kBlock) lvlL[j] = lp[j];
 }
 
-// reference cedr_qlt_inl.hpp:69-99 (r2l_nl_adjust_bounds)
-__device__ void adjust_bounds (double& b0, double& b1, const double rh0, const double rh1,
-                               const double extra) {
-  const double q0 = b0/rh0, q1 = b1/rh1;
-  if (extra < 0) {
-    const bool first = q0 >= q1;  // i0 = 0 if first
-    const double gap = first ? (q1 - q0)*rh0 : (q0 - q1)*rh1;
-    if (gap <= extra) { if (first) b0 += extra; else b1 += extra; return; }
-  } else {
-    const bool first = q0 <= q1;
-    const double gap = first ? (q1 - q0)*rh0 : (q0 - q1)*rh1;
-    if (gap >= extra) { if (first) b0 += extra; else b1 += extra; return; }
-  }
-  const double tot = b0 + b1 + extra;
-  const double rtot = rh0 + rh1;
-  const double qt = tot/rtot;
-  b0 = qt*rh0;
-  b1 = qt*rh1;
-}
+template <int N> struct Log2 { enum { value = 1 + Log2<N/2>::value }; };
+template <> struct Log2<1> { enum { value = 0 }; };
 
-// reference cedr_qlt_inl.hpp:120-173 (mass form of the node problem)
-__device__ void node_problem_mass (const double p_lo, const double p_orig, const double p_hi,
-                                   const double Qm,
-                                   const double rh0, double lo0, const double or0, double hi0,
-                                   const double rh1, double lo1, const double or1, double hi1,
-                                   double& x0, double& x1, const bool prefer) {
-  const bool below = Qm < p_lo, above = Qm > p_hi;
-  if (below || above) {
-    const double tol = 10*kEps;
-    const double disc = below ? p_lo - Qm : Qm - p_hi;
-    if (disc > tol*(p_hi - p_lo)) {
-      if (below) adjust_bounds(lo0, lo1, rh0, rh1, Qm - p_lo);
-      else       adjust_bounds(hi0, hi1, rh0, rh1, Qm - p_hi);
-    }
-  } else if (Qm == p_orig && or0 >= lo0 && or0 <= hi0 && or1 >= lo1 && or1 <= hi1) {
-    x0 = or0;
-    x1 = or1;
-    return;
-  }
-  x0 = or0;
-  x1 = or1;
-  qp_2d(1.0/rh0, 1.0/rh1, Qm, lo0, lo1, hi0, hi1, or0, or1, x0, x1, ! prefer, ! prefer);
-}
-
-// reference cedr_qlt_inl.hpp:175-203 (dispatch on problem type)
-__device__ void solve_node (const int pt, const double rh, const double p_lo,
-                            const double p_orig, const double p_hi, const double Qm,
-                            const double rh0, const double lo0, const double or0, const double hi0,
-                            const double rh1, const double lo1, const double or1, const double hi1,
-                            double& x0, double& x1, const bool prefer) {
-  if ((pt & CONSISTENT) && ! (pt & SHAPEPRESERVE)) {
-    node_problem_mass(p_lo*rh, p_orig, p_hi*rh, Qm,
-                      rh0, lo0*rh0, or0, hi0*rh0, rh1, lo1*rh1, or1, hi1*rh1, x0, x1, prefer);
-  } else if (pt & NONNEGATIVE) {
-    // solve_1eq_nonneg(2, ones, Qm, y, x, w, least_squares), cedr_local_inl.hpp:309-330
-    x0 = or0;
-    x1 = or1;
-    if (Qm < 0) return;
-    qp_2d(1.0/rh0, 1.0/rh1, Qm, 0.0, 0.0, Qm, Qm, or0, or1, x0, x1, true, true);
-  } else {
-    node_problem_mass(p_lo, p_orig, p_hi, Qm, rh0, lo0, or0, hi0, rh1, lo1, or1, hi1,
-                      x0, x1, prefer);
-  }
-}
-
-// --------------------------------------------------------- leaves -> root sweep
-// One workgroup = one tile x a group of F fields. A wave owns whole fields;
-// its lanes stride over the nodes of a level.
-template <int F>
+// Leaves -> root. FT fields per chunk (power of 2), NI input loads per lane and
+// row (tiles have at most 64*NI inputs), pitch = LDS doubles per field row.
+template <int FT, int NI>
 __global__ __launch_bounds__(kBlock)
 void tree_up_kernel (const cedr_hip_stage st, const int nfields, const uint8_t* __restrict__ op,
-                     const int64_t stride, double* __restrict__ data, const int zero_init) {
+                     const int64_t stride, double* __restrict__ data, const int zero_init,
+                     const int pitch) {
   extern __shared__ double lds[];
   const cedr_hip_tile tile = st.tiles[blockIdx.x];
-  const int MN = st.max_nodes;
-  const int f0 = blockIdx.y*F;
-  const int nf = min(F, nfields - f0);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & (kWave - 1);
-  const uint16_t* __restrict__ kids = st.kids + 2*static_cast<size_t>(tile.kids_off);
-  const int32_t* __restrict__ lvlptr = st.lvlptr + tile.lvl_off;
+  uint32_t* const kidsL = reinterpret_cast<uint32_t*>(lds);
+  int32_t* const lvlL = reinterpret_cast<int32_t*>(kidsL + st.max_nint);
+  double* const v = lds + (st.max_nint + 1);
   const int nleaf = tile.nleaf;
+  const int nchunks = (nfields + FT - 1)/FT;
+  const double* __restrict__ src0 = data + tile.in0;
+  constexpr int NR = FT/kNW;  // field rows a wave loads per chunk
 
-  for (int f = wave; f < nf; f += kBlock/kWave) {
-    const double* __restrict__ src = data + static_cast<size_t>(f0 + f)*stride + tile.in0;
-    double* v = lds + f*MN;
-    for (int i = lane; i < nleaf; i += kWave) v[i] = src[i];
-  }
-  __syncthreads();
-  for (int lv = 0; lv < tile.nlvl; ++lv) {
-    const int a = lvlptr[lv], b = lvlptr[lv+1];
-    for (int f = wave; f < nf; f += kBlock/kWave) {
-      double* v = lds + f*MN;
-      const int o = op[f0 + f];
-      for (int j = a + lane; j < b; j += kWave) {
-        const double k0 = v[kids[2*j]], k1 = v[kids[2*j+1]];
+  auto load = [&] (const int c, double (&buf)[NR][NI]) {
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      const int f = c*FT + wave + kNW*r;
+#pragma unroll
+      for (int it = 0; it < NI; ++it) {
+        const int i = lane + kWave*it;
+        buf[r][it] = (f < nfields && i < nleaf) ? src0[static_cast<size_t>(f)*stride + i] : 0.0;
+      }
+    }
+  };
+
+  double cur[NR][NI];
+  if (static_cast<int>(blockIdx.y) < nchunks) load(blockIdx.y, cur);
+  stage_tile_meta(st, tile, kidsL, lvlL);
+  const int root = tile.nint ? nleaf + tile.nint - 1 : 0;
+  const int ff = threadIdx.x & (FT - 1);  // this thread's field within a chunk
+  double* const vf = v + ff*pitch;
+
+  for (int c = blockIdx.y; c < nchunks; c += gridDim.y) {
+    double nxt[NR][NI];
+    const int cn = c + gridDim.y;
+    if (cn < nchunks) load(cn, nxt);
+    const int f = c*FT + ff;
+    const int o = f < nfields ? op[f] : 0;
+#pragma unroll
+    for (int r = 0; r < NR; ++r)
+#pragma unroll
+      for (int it = 0; it < NI; ++it) {
+        const int i = lane + kWave*it;
+        if (i < nleaf) v[(wave + kNW*r)*pitch + i] = cur[r][it];
+      }
+    __syncthreads();
+    for (int lv = 0; lv < tile.nlvl; ++lv) {
+      const int a = lvlL[lv];
+      const int nitems = (lvlL[lv+1] - a) << Log2<FT>::value;
+      for (int q = threadIdx.x; q < nitems; q += kBlock) {
+        const int j = a + (q >> Log2<FT>::value);
+        const uint32_t kk = kidsL[j];
+        const double k0 = vf[kk & 0xffff], k1 = vf[kk >> 16];
         double r;
         if (o == 0) {
           if (zero_init) { r = 0; r += k0; r += k1; }
           else r = k0 + k1;
         } else if (o == 1) r = rmin(k0, k1);
         else r = rmax(k0, k1);
-        v[nleaf + j] = r;
+        vf[nleaf + j] = r;
       }
+      __syncthreads();
     }
-    __syncthreads();
+    if (threadIdx.x < FT && f < nfields)
+      data[static_cast<size_t>(f)*stride + tile.out] = vf[root];
+    __syncthreads();  // the next chunk overwrites v
+#pragma unroll
+    for (int r = 0; r < NR; ++r)
+#pragma unroll
+      for (int it = 0; it < NI; ++it) cur[r][it] = nxt[r][it];
   }
-  const int root = tile.nint ? nleaf + tile.nint - 1 : 0;
-  if (threadIdx.x < nf)
-    data[static_cast<size_t>(f0 + threadIdx.x)*stride + tile.out] = lds[threadIdx.x*MN + root];
 }
 
-// --------------------------------------------------------- root -> leaves sweep
-// One workgroup = one tile x T tracers (bulk order). LDS per tracer: a record
-// {lo, orig, hi, X} per node (RS doubles apart), plus rhom per node.
-template <int T, int RS>
+// Root -> leaves. TT tracers (bulk order) per chunk; per tracer and node an LDS
+// record {lo, orig, hi, X} of 4 doubles, tracer rows 'pitch' doubles apart.
+// Shared per tile: rhom, 1/rhom and 1/(1/rhom) of every node -- the only
+// divisions of the common path besides one per node problem.
+template <int TT, int NI>
 __global__ __launch_bounds__(kBlock)
 void qlt_down_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st,
-                      double* __restrict__ l2r, double* __restrict__ r2l) {
+                      double* __restrict__ l2r, double* __restrict__ r2l, const int pitch) {
   extern __shared__ double lds[];
   const cedr_hip_tile tile = st.tiles[blockIdx.x];
   const int MN = st.max_nodes;
-  double* const rho = lds;
-  double* const recs = lds + ((MN + 1) & ~1);
-  const int bi0 = blockIdx.y*T;
-  const int ntr = min(T, L.nt - bi0);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & (kWave - 1);
-  constexpr int NW = kBlock/kWave;
-  const uint16_t* __restrict__ kids = st.kids + 2*static_cast<size_t>(tile.kids_off);
-  const int32_t* __restrict__ lvlptr = st.lvlptr + tile.lvl_off;
+  uint32_t* const kidsL = reinterpret_cast<uint32_t*>(lds);
+  int32_t* const lvlL = reinterpret_cast<int32_t*>(kidsL + st.max_nint);
+  double* const rho = lds + (st.max_nint + 1);
+  double* const rw = rho + MN;
+  double* const rq = rw + MN;
+  double* const recs = rq + MN;
   const int nleaf = tile.nleaf;
   const int64_t S = L.stride;
   const bool prefer = L.prefer_mass_con != 0;
+  const int nt = L.nt;
+  const int nchunks = (nt + TT - 1)/TT;
+  constexpr int NR = 3*TT/kNW;  // (tracer, field) rows a wave loads per chunk
 
-  // Phase 0: inputs' records from HBM. Row ntr is rhom.
-  for (int row = wave; row <= ntr; row += NW) {
-    if (row == ntr) {
-      const double* __restrict__ src = l2r + tile.in0;
-      for (int i = lane; i < nleaf; i += kWave) rho[i] = src[i];
-      continue;
-    }
-    const int pt = L.bidx_prob[bi0 + row], lb = L.bidx_l2r[bi0 + row];
-    double* R = recs + static_cast<size_t>(row)*MN*RS;
-    if (pt & SHAPEPRESERVE) {
-      const double* __restrict__ s0 = l2r + static_cast<size_t>(lb)*S + tile.in0;
-      const double* __restrict__ s1 = s0 + S;
-      const double* __restrict__ s2 = s1 + S;
-      for (int i = lane; i < nleaf; i += kWave) {
-        R[i*RS] = s0[i]; R[i*RS+1] = s1[i]; R[i*RS+2] = s2[i];
+  // Row rr = 3*tt + fld of a chunk: fld 0/1/2 = lo/orig/hi of a shapepreserve
+  // tracer. Other tracers only have 'orig' (consistent-only: l2r field 1, its q
+  // bounds come from the root; nonnegative: l2r field 0).
+  auto load = [&] (const int c, double (&buf)[NR][NI]) {
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      const int rr = wave + kNW*r;
+      const int bi = c*TT + rr/3, fld = rr % 3;
+      bool want = bi < nt;
+      int field = 0;
+      if (want) {
+        const int pt = L.bidx_prob[bi];
+        const bool sp = (pt & SHAPEPRESERVE) != 0;
+        want = sp || fld == 1;
+        field = L.bidx_l2r[bi] + (sp ? fld : ((pt & CONSISTENT) ? 1 : 0));
       }
-    } else {
-      // consistent-only: orig is field 1, q bounds come from the root;
-      // nonnegative: orig is field 0.
-      const int of = (pt & CONSISTENT) ? 1 : 0;
-      const double* __restrict__ s1 = l2r + static_cast<size_t>(lb + of)*S + tile.in0;
-      for (int i = lane; i < nleaf; i += kWave) R[i*RS+1] = s1[i];
+      const double* __restrict__ s0 = l2r + static_cast<size_t>(field)*S + tile.in0;
+#pragma unroll
+      for (int it = 0; it < NI; ++it) {
+        const int i = lane + kWave*it;
+        buf[r][it] = (want && i < nleaf) ? s0[i] : 0.0;
+      }
     }
+  };
+
+  double cur[NR][NI];
+  if (static_cast<int>(blockIdx.y) < nchunks) load(blockIdx.y, cur);
+  {
+    const double* __restrict__ src = l2r + tile.in0;
+    for (int i = threadIdx.x; i < nleaf; i += kBlock) rho[i] = src[i];
   }
+  stage_tile_meta(st, tile, kidsL, lvlL);
   __syncthreads();
-
-  // Phase A: re-form the sums of the tile's internal nodes (what the
-  // leaves->root sweep computed but did not store).
   for (int lv = 0; lv < tile.nlvl; ++lv) {
-    const int a = lvlptr[lv], b = lvlptr[lv+1];
-    for (int row = wave; row <= ntr; row += NW) {
-      if (row == ntr) {
-        for (int j = a + lane; j < b; j += kWave)
-          rho[nleaf + j] = rho[kids[2*j]] + rho[kids[2*j+1]];
-        continue;
-      }
-      const int pt = L.bidx_prob[bi0 + row];
-      double* R = recs + static_cast<size_t>(row)*MN*RS;
-      if (pt & SHAPEPRESERVE) {
-        for (int j = a + lane; j < b; j += kWave) {
-          const double* k0 = R + kids[2*j]*RS;
-          const double* k1 = R + kids[2*j+1]*RS;
-          double* me = R + (nleaf + j)*RS;
-          me[0] = k0[0] + k1[0];
-          me[1] = k0[1] + k1[1];
-          me[2] = k0[2] + k1[2];
-        }
-      } else {
-        for (int j = a + lane; j < b; j += kWave)
-          R[(nleaf + j)*RS + 1] = R[kids[2*j]*RS + 1] + R[kids[2*j+1]*RS + 1];
-      }
+    const int a = lvlL[lv], b = lvlL[lv+1];
+    for (int j = a + threadIdx.x; j < b; j += kBlock) {
+      const uint32_t kk = kidsL[j];
+      rho[nleaf + j] = rho[kk & 0xffff] + rho[kk >> 16];
     }
     __syncthreads();
   }
-
-  // Phase B: the tile root's assigned mass, then node problems level by level.
-  const int root = tile.nint ? nleaf + tile.nint - 1 : 0;
-  if (threadIdx.x < ntr) {
-    const int rb = L.bidx_r2l[bi0 + threadIdx.x];
-    recs[(static_cast<size_t>(threadIdx.x)*MN + root)*RS + 3] =
-      r2l[static_cast<size_t>(rb)*S + tile.out];
+  for (int i = threadIdx.x; i < nleaf + tile.nint; i += kBlock) {
+    const double w = 1.0/rho[i];
+    rw[i] = w;
+    rq[i] = 1.0/w;
   }
-  __syncthreads();
-  for (int lv = tile.nlvl - 1; lv >= 0; --lv) {
-    const int a = lvlptr[lv], b = lvlptr[lv+1];
-    for (int row = wave; row < ntr; row += NW) {
-      const int pt = L.bidx_prob[bi0 + row];
-      double* R = recs + static_cast<size_t>(row)*MN*RS;
-      double qlo = 0, qhi = 0;
-      const bool t_only = (pt & CONSISTENT) && ! (pt & SHAPEPRESERVE);
+  const int root = tile.nint ? nleaf + tile.nint - 1 : 0;
+  const int tt = threadIdx.x & (TT - 1);  // this thread's tracer within a chunk
+  double* const R = recs + tt*pitch;
+
+  for (int c = blockIdx.y; c < nchunks; c += gridDim.y) {
+    double nxt[NR][NI];
+    const int cn = c + gridDim.y;
+    if (cn < nchunks) load(cn, nxt);
+    const int bi = c*TT + tt;
+    const bool live = bi < nt;
+    const int pt = live ? L.bidx_prob[bi] : (SHAPEPRESERVE | CONSISTENT);
+    const int rb = live ? L.bidx_r2l[bi] : 0;
+    const bool sp = (pt & SHAPEPRESERVE) != 0;
+    const bool t_only = (pt & CONSISTENT) && ! sp;
+    // The tile root's assigned mass, and for a t-only tracer the global q
+    // bounds, which travel root->leaves unchanged (cedr_qlt.cpp:549-560).
+    double Xroot = 0, qlo = 0, qhi = 0;
+    if (live) {
+      Xroot = r2l[static_cast<size_t>(rb)*S + tile.out];
       if (t_only) {
-        // Global q_min/q_max travel root->leaves unchanged (cedr_qlt.cpp:549-560).
-        const int rb = L.bidx_r2l[bi0 + row];
         qlo = r2l[static_cast<size_t>(rb + 1)*S + tile.out];
         qhi = r2l[static_cast<size_t>(rb + 2)*S + tile.out];
       }
-      for (int j = a + lane; j < b; j += kWave) {
-        const int c0 = kids[2*j], c1 = kids[2*j+1], me = nleaf + j;
-        const double* P = R + me*RS;
-        double* K0 = R + c0*RS;
-        double* K1 = R + c1*RS;
+    }
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      const int rr = wave + kNW*r;
+      double* const Rr = recs + (rr/3)*pitch + rr % 3;
+#pragma unroll
+      for (int it = 0; it < NI; ++it) {
+        const int i = lane + kWave*it;
+        if (i < nleaf) Rr[4*i] = cur[r][it];
+      }
+    }
+    __syncthreads();  // also orders rho/rw/rq before their first use
+    // Phase A: re-form the sums of the tile's internal nodes.
+    for (int lv = 0; lv < tile.nlvl; ++lv) {
+      const int a = lvlL[lv];
+      const int nitems = (lvlL[lv+1] - a) << Log2<TT>::value;
+      for (int q = threadIdx.x; q < nitems; q += kBlock) {
+        const int j = a + (q >> Log2<TT>::value);
+        const uint32_t kk = kidsL[j];
+        const double* K0 = R + 4*(kk & 0xffff);
+        const double* K1 = R + 4*(kk >> 16);
+        double* me = R + 4*(nleaf + j);
+        if (sp) { me[0] = K0[0] + K1[0]; me[2] = K0[2] + K1[2]; }
+        me[1] = K0[1] + K1[1];
+      }
+      __syncthreads();
+    }
+    // Phase B: node problems, level by level from the tile root.
+    if (threadIdx.x < TT) R[4*root + 3] = Xroot;
+    __syncthreads();
+    for (int lv = tile.nlvl - 1; lv >= 0; --lv) {
+      const int a = lvlL[lv];
+      const int nitems = (lvlL[lv+1] - a) << Log2<TT>::value;
+      for (int q = threadIdx.x; q < nitems; q += kBlock) {
+        const int j = a + (q >> Log2<TT>::value);
+        const uint32_t kk = kidsL[j];
+        const int c0 = kk & 0xffff, c1 = kk >> 16, me = nleaf + j;
+        const KidRho r0{rho[c0], rw[c0], rq[c0]}, r1{rho[c1], rw[c1], rq[c1]};
+        const double* P = R + 4*me;
+        double* K0 = R + 4*c0;
+        double* K1 = R + 4*c1;
         double x0, x1;
         if (t_only)
-          solve_node(pt, rho[me], qlo, P[1], qhi, P[3], rho[c0], qlo, K0[1], qhi,
-                     rho[c1], qlo, K1[1], qhi, x0, x1, prefer);
+          solve_node(pt, rho[me], qlo, P[1], qhi, P[3], r0, qlo, K0[1], qhi,
+                     r1, qlo, K1[1], qhi, x0, x1, prefer);
         else
-          solve_node(pt, rho[me], P[0], P[1], P[2], P[3], rho[c0], K0[0], K0[1], K0[2],
-                     rho[c1], K1[0], K1[1], K1[2], x0, x1, prefer);
+          solve_node(pt, rho[me], P[0], P[1], P[2], P[3], r0, K0[0], K0[1], K0[2],
+                     r1, K1[0], K1[1], K1[2], x0, x1, prefer);
         K0[3] = x0;
         K1[3] = x1;
       }
+      __syncthreads();
     }
-    __syncthreads();
-  }
-
-  // Phase C: inputs' masses back to HBM.
-  for (int row = wave; row < ntr; row += NW) {
-    const int pt = L.bidx_prob[bi0 + row], rb = L.bidx_r2l[bi0 + row];
-    const double* R = recs + static_cast<size_t>(row)*MN*RS;
-    double* __restrict__ dst = r2l + static_cast<size_t>(rb)*S + tile.in0;
-    for (int i = lane; i < nleaf; i += kWave) dst[i] = R[i*RS + 3];
-    if ((pt & CONSISTENT) && ! (pt & SHAPEPRESERVE)) {
-      const int lb = L.bidx_l2r[bi0 + row];
-      const double qlo = r2l[static_cast<size_t>(rb + 1)*S + tile.out];
-      const double qhi = r2l[static_cast<size_t>(rb + 2)*S + tile.out];
-      double* __restrict__ r1 = dst + S;
-      double* __restrict__ r2 = r1 + S;
-      double* __restrict__ l0 = l2r + static_cast<size_t>(lb)*S + tile.in0;
-      double* __restrict__ l2 = l0 + 2*S;
-      for (int i = lane; i < nleaf; i += kWave) {
-        r1[i] = qlo; r2[i] = qhi; l0[i] = qlo; l2[i] = qhi;
+    // Phase C: inputs' masses back to HBM, one tracer row per wave pass.
+    for (int t2 = wave; t2 < TT; t2 += kNW) {
+      const int b2 = c*TT + t2;
+      if (b2 >= nt) break;
+      const int pt2 = L.bidx_prob[b2], rb2 = L.bidx_r2l[b2];
+      const double* R2 = recs + t2*pitch;
+      double* __restrict__ dst = r2l + static_cast<size_t>(rb2)*S + tile.in0;
+      for (int i = lane; i < nleaf; i += kWave) dst[i] = R2[4*i + 3];
+      if ((pt2 & CONSISTENT) && ! (pt2 & SHAPEPRESERVE)) {
+        const double ql = r2l[static_cast<size_t>(rb2 + 1)*S + tile.out];
+        const double qh = r2l[static_cast<size_t>(rb2 + 2)*S + tile.out];
+        double* __restrict__ l0 = l2r + static_cast<size_t>(L.bidx_l2r[b2])*S + tile.in0;
+        for (int i = lane; i < nleaf; i += kWave) {
+          dst[S + i] = ql; dst[2*S + i] = qh; l0[i] = ql; l0[2*S + i] = qh;
+        }
       }
     }
+    __syncthreads();  // the next chunk overwrites the records
+#pragma unroll
+    for (int r = 0; r < NR; ++r)
+#pragma unroll
+      for (int it = 0; it < NI; ++it) cur[r][it] = nxt[r][it];
   }
 }
 
@@ -627,6 +567,45 @@ void caas_finish_kernel (const int nt, const int n, double* __restrict__ d,
   }
 }
 
+
+// ------------------------------------------------------------ launch profiler
+// Optional HIP-event timing of every layer-K launch, on the stream the kernel
+// is launched on. Off by default; bench.py switches it on for its roofline leg.
+enum KernelId : int { K_TREE_UP = 0, K_QLT_DOWN, K_QLT_ROOT, K_GATHER, K_SCATTER, K_COPY,
+                      K_SET_RHOM, K_SET_QM, K_GET_QM, K_CAAS_REDUCE, K_CAAS_SUM, K_CAAS_ACCUM,
+                      K_CAAS_FINISH, K_COUNT };
+const char* const kKernelNames[K_COUNT] = {
+  "tree_up_kernel", "qlt_down_kernel", "qlt_root_kernel", "gather_slots_kernel",
+  "scatter_slots_kernel", "copy_slots_kernel", "qlt_set_rhom_kernel", "qlt_set_Qm_kernel",
+  "qlt_get_Qm_kernel", "caas_reduce_kernel", "caas_sum_partials_kernel",
+  "caas_reduce_accum_kernel", "caas_finish_kernel" };
+
+struct ProfRec { int id; int64_t aux; hipEvent_t a, b; };
+struct Profiler {
+  bool on = false;
+  std::vector<ProfRec> recs;
+  std::vector<hipEvent_t> pool;
+  hipEvent_t get () {
+    if ( ! pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+    hipEvent_t e;
+    (void) hipEventCreate(&e);
+    return e;
+  }
+};
+Profiler g_prof;
+
+struct ProfScope {
+  hipStream_t s;
+  bool on;
+  ProfScope (int id, int64_t aux, hipStream_t stream) : s(stream), on(g_prof.on) {
+    if ( ! on) return;
+    ProfRec r{id, aux, g_prof.get(), g_prof.get()};
+    (void) hipEventRecord(r.a, s);
+    g_prof.recs.push_back(r);
+  }
+  ~ProfScope () { if (on) (void) hipEventRecord(g_prof.recs.back().b, s); }
+};
+
 inline int launch_status () { return static_cast<int>(hipGetLastError()); }
 
 template <typename K>
@@ -637,9 +616,19 @@ int set_lds_limit (K kernel, size_t bytes) {
                                               static_cast<int>(bytes)));
 }
 
-constexpr int kUpFields = 16;    // fields per workgroup, leaves->root
-constexpr int kDownTracers = 4;  // tracers per workgroup, root->leaves
-constexpr int kRecStride = 5;    // doubles between node records in LDS (odd: spreads banks)
+constexpr int kUpFT = 32;    // fields per chunk, leaves->root
+constexpr int kDownTT = 8;   // tracers per chunk, root->leaves
+
+// kid pairs (4 B each) + level offsets (4 B each), rounded up to doubles
+inline size_t meta_doubles (const cedr_hip_stage* st) { return static_cast<size_t>(st->max_nint) + 1; }
+// smallest p >= n with p == 1 (mod 32)
+inline int pitch_for (int n) { return (n + 30)/32*32 + 1; }
+// Spread the chunks of a stage with few tiles over more workgroups.
+inline int chunk_split (int ntiles, int nchunks) {
+  int y = (1024 + ntiles - 1)/ntiles;
+  if (y > nchunks) y = nchunks;
+  return y < 1 ? 1 : y;
+}
 
 }  // namespace
 
@@ -647,34 +636,54 @@ extern "C" {
 
 int cedr_hip_tree_up (const cedr_hip_stage* st, int32_t nfields, const uint8_t* op,
                       int64_t stride, double* data, int zero_init, cedr_stream_t stream) {
+  ProfScope ps(K_TREE_UP, st->ntiles, stream);
   if (st->ntiles == 0 || nfields == 0) return 0;
-  const size_t lds = sizeof(double)*kUpFields*static_cast<size_t>(st->max_nodes);
+  if (st->max_nleaf > 256) return static_cast<int>(hipErrorInvalidValue);
+  const int pitch = pitch_for(st->max_nodes);
+  const size_t lds = sizeof(double)*(meta_doubles(st) + static_cast<size_t>(kUpFT)*pitch);
   if (lds > 160*1024) return static_cast<int>(hipErrorInvalidValue);
-  int e = set_lds_limit(tree_up_kernel<kUpFields>, lds);
-  if (e) return e;
-  const dim3 grid(st->ntiles, (nfields + kUpFields - 1)/kUpFields);
-  hipLaunchKernelGGL(tree_up_kernel<kUpFields>, grid, dim3(kBlock), lds, stream,
-                     *st, nfields, op, stride, data, zero_init);
+  const dim3 grid(st->ntiles, chunk_split(st->ntiles, (nfields + kUpFT - 1)/kUpFT));
+  if (st->max_nleaf <= 128) {
+    int e = set_lds_limit(tree_up_kernel<kUpFT, 2>, lds);
+    if (e) return e;
+    hipLaunchKernelGGL((tree_up_kernel<kUpFT, 2>), grid, dim3(kBlock), lds, stream,
+                       *st, nfields, op, stride, data, zero_init, pitch);
+  } else {
+    int e = set_lds_limit(tree_up_kernel<kUpFT, 4>, lds);
+    if (e) return e;
+    hipLaunchKernelGGL((tree_up_kernel<kUpFT, 4>), grid, dim3(kBlock), lds, stream,
+                       *st, nfields, op, stride, data, zero_init, pitch);
+  }
   return launch_status();
 }
 
 int cedr_hip_qlt_down (const cedr_hip_qlt_layout* lay, const cedr_hip_stage* st,
                        double* l2r, double* r2l, cedr_stream_t stream) {
+  ProfScope ps(K_QLT_DOWN, st->ntiles, stream);
   if (st->ntiles == 0) return 0;
+  if (st->max_nleaf > 256) return static_cast<int>(hipErrorInvalidValue);
   const size_t mn = st->max_nodes;
-  const size_t lds = sizeof(double)*(((mn + 1) & ~static_cast<size_t>(1)) +
-                                     kDownTracers*mn*kRecStride);
+  const int pitch = pitch_for(4*st->max_nodes);
+  const size_t lds = sizeof(double)*(meta_doubles(st) + 3*mn + static_cast<size_t>(kDownTT)*pitch);
   if (lds > 160*1024) return static_cast<int>(hipErrorInvalidValue);
-  int e = set_lds_limit(qlt_down_kernel<kDownTracers, kRecStride>, lds);
-  if (e) return e;
-  const dim3 grid(st->ntiles, (lay->nt + kDownTracers - 1)/kDownTracers);
-  hipLaunchKernelGGL((qlt_down_kernel<kDownTracers, kRecStride>), grid, dim3(kBlock), lds, stream,
-                     *lay, *st, l2r, r2l);
+  const dim3 grid(st->ntiles, chunk_split(st->ntiles, (lay->nt + kDownTT - 1)/kDownTT));
+  if (st->max_nleaf <= 128) {
+    int e = set_lds_limit(qlt_down_kernel<kDownTT, 2>, lds);
+    if (e) return e;
+    hipLaunchKernelGGL((qlt_down_kernel<kDownTT, 2>), grid, dim3(kBlock), lds, stream,
+                       *lay, *st, l2r, r2l, pitch);
+  } else {
+    int e = set_lds_limit(qlt_down_kernel<kDownTT, 4>, lds);
+    if (e) return e;
+    hipLaunchKernelGGL((qlt_down_kernel<kDownTT, 4>), grid, dim3(kBlock), lds, stream,
+                       *lay, *st, l2r, r2l, pitch);
+  }
   return launch_status();
 }
 
 int cedr_hip_qlt_root (const cedr_hip_qlt_layout* lay, int32_t root_slot, const double* l2r,
                        double* r2l, cedr_stream_t stream) {
+  ProfScope ps(K_QLT_ROOT, 0, stream);
   hipLaunchKernelGGL(qlt_root_kernel, dim3((lay->nt + 63)/64), dim3(64), 0, stream,
                      *lay, root_slot, l2r, r2l);
   return launch_status();
@@ -682,6 +691,7 @@ int cedr_hip_qlt_root (const cedr_hip_qlt_layout* lay, int32_t root_slot, const 
 
 int cedr_hip_gather_slots (const double* data, int64_t stride, int32_t nfields,
                            const int32_t* slots, int32_t n, double* out, cedr_stream_t stream) {
+  ProfScope ps(K_GATHER, n, stream);
   if (n*nfields == 0) return 0;
   hipLaunchKernelGGL(gather_slots_kernel, dim3((n*nfields + kBlock - 1)/kBlock), dim3(kBlock), 0,
                      stream, data, stride, nfields, slots, n, out);
@@ -690,6 +700,7 @@ int cedr_hip_gather_slots (const double* data, int64_t stride, int32_t nfields,
 
 int cedr_hip_scatter_slots (double* data, int64_t stride, int32_t nfields, const int32_t* slots,
                             int32_t n, const double* in, cedr_stream_t stream) {
+  ProfScope ps(K_SCATTER, n, stream);
   if (n*nfields == 0) return 0;
   hipLaunchKernelGGL(scatter_slots_kernel, dim3((n*nfields + kBlock - 1)/kBlock), dim3(kBlock), 0,
                      stream, data, stride, nfields, slots, n, in);
@@ -699,6 +710,7 @@ int cedr_hip_scatter_slots (double* data, int64_t stride, int32_t nfields, const
 int cedr_hip_scatter_slots_fm (double* data, int64_t stride, int32_t nfields,
                                const int32_t* slots, int32_t n, const double* in,
                                cedr_stream_t stream) {
+  ProfScope ps(K_SCATTER, n, stream);
   if (n*nfields == 0) return 0;
   hipLaunchKernelGGL(scatter_slots_fm_kernel, dim3((n*nfields + kBlock - 1)/kBlock), dim3(kBlock),
                      0, stream, data, stride, nfields, slots, n, in);
@@ -707,6 +719,7 @@ int cedr_hip_scatter_slots_fm (double* data, int64_t stride, int32_t nfields,
 
 int cedr_hip_copy_slots (double* data, int64_t stride, int32_t nfields, const int32_t* src,
                          const int32_t* dst, int32_t n, cedr_stream_t stream) {
+  ProfScope ps(K_COPY, n, stream);
   if (n*nfields == 0) return 0;
   hipLaunchKernelGGL(copy_slots_kernel, dim3((n*nfields + kBlock - 1)/kBlock), dim3(kBlock), 0,
                      stream, data, stride, nfields, src, dst, n);
@@ -715,6 +728,7 @@ int cedr_hip_copy_slots (double* data, int64_t stride, int32_t nfields, const in
 
 int cedr_hip_qlt_set_rhom (int64_t, int32_t n, const double* rhom, double* l2r,
                            cedr_stream_t stream) {
+  ProfScope ps(K_SET_RHOM, n, stream);
   hipLaunchKernelGGL(qlt_set_rhom_kernel, dim3((n + kBlock - 1)/kBlock), dim3(kBlock), 0, stream,
                      n, rhom, l2r);
   return launch_status();
@@ -724,6 +738,7 @@ int cedr_hip_qlt_set_Qm (int32_t nt, const int32_t* trcr_prob, const int32_t* tr
                          int64_t stride, int32_t n, const double* Qm, const double* Qm_min,
                          const double* Qm_max, const double* Qm_prev, double* l2r,
                          cedr_stream_t stream) {
+  ProfScope ps(K_SET_QM, n, stream);
   const int gx = (n + kBlock - 1)/kBlock;
   hipLaunchKernelGGL(qlt_set_Qm_kernel, dim3(gx < 1024 ? gx : 1024, nt), dim3(kBlock), 0, stream,
                      trcr_prob, trcr_l2r, stride, n, Qm, Qm_min, Qm_max, Qm_prev, l2r);
@@ -732,6 +747,7 @@ int cedr_hip_qlt_set_Qm (int32_t nt, const int32_t* trcr_prob, const int32_t* tr
 
 int cedr_hip_qlt_get_Qm (int32_t nt, const int32_t* trcr_r2l, int64_t stride, int32_t n,
                          const double* r2l, double* Qm_out, cedr_stream_t stream) {
+  ProfScope ps(K_GET_QM, n, stream);
   const int gx = (n + kBlock - 1)/kBlock;
   hipLaunchKernelGGL(qlt_get_Qm_kernel, dim3(gx < 1024 ? gx : 1024, nt), dim3(kBlock), 0, stream,
                      trcr_r2l, stride, n, r2l, Qm_out);
@@ -743,6 +759,7 @@ int32_t cedr_hip_caas_nchunks (int32_t n) { return (n + kCaasChunk - 1)/kCaasChu
 int cedr_hip_caas_reduce_local (const int32_t* probs, int32_t nt, int32_t n, int need_conserve,
                                 double* d, const double* qm_src, double* partials,
                                 cedr_stream_t stream) {
+  ProfScope ps(K_CAAS_REDUCE, n, stream);
   const dim3 grid(cedr_hip_caas_nchunks(n), nt);
   const bool vec = n % 2 == 0 && reinterpret_cast<uintptr_t>(d) % 16 == 0 &&
     ( ! qm_src || reinterpret_cast<uintptr_t>(qm_src) % 16 == 0);
@@ -757,6 +774,7 @@ int cedr_hip_caas_reduce_local (const int32_t* probs, int32_t nt, int32_t n, int
 
 int cedr_hip_caas_sum_partials (int32_t nt, int32_t n, const double* partials, double* send,
                                 cedr_stream_t stream) {
+  ProfScope ps(K_CAAS_SUM, n, stream);
   hipLaunchKernelGGL(caas_sum_partials_kernel, dim3(4*nt), dim3(kWave), 0, stream,
                      cedr_hip_caas_nchunks(n), partials, send);
   return launch_status();
@@ -765,6 +783,7 @@ int cedr_hip_caas_sum_partials (int32_t nt, int32_t n, const double* partials, d
 int cedr_hip_caas_reduce_local_accum (const int32_t* probs, int32_t nt, int32_t n,
                                       int need_conserve, int32_t na, double* d, double* send,
                                       cedr_stream_t stream) {
+  ProfScope ps(K_CAAS_ACCUM, n, stream);
   if (na < 1 || n % na) return static_cast<int>(hipErrorInvalidValue);
   const int total = 2*nt*(n/na);
   hipLaunchKernelGGL(caas_reduce_accum_kernel, dim3((total + kBlock - 1)/kBlock), dim3(kBlock), 0,
@@ -774,6 +793,7 @@ int cedr_hip_caas_reduce_local_accum (const int32_t* probs, int32_t nt, int32_t 
 
 int cedr_hip_caas_finish_local (int32_t nt, int32_t n, double* d, const double* recv,
                                 cedr_stream_t stream) {
+  ProfScope ps(K_CAAS_FINISH, n, stream);
   const dim3 grid(cedr_hip_caas_nchunks(n), nt);
   const bool vec = n % 2 == 0 && reinterpret_cast<uintptr_t>(d) % 16 == 0;
   if (vec)
@@ -781,6 +801,30 @@ int cedr_hip_caas_finish_local (int32_t nt, int32_t n, double* d, const double* 
   else
     hipLaunchKernelGGL(caas_finish_kernel<1>, grid, dim3(kBlock), 0, stream, nt, n, d, recv);
   return launch_status();
+}
+
+void cedr_hip_profile_start (void) {
+  for (auto& r : g_prof.recs) { g_prof.pool.push_back(r.a); g_prof.pool.push_back(r.b); }
+  g_prof.recs.clear();
+  g_prof.on = true;
+}
+
+int cedr_hip_profile_stop (void) {
+  g_prof.on = false;
+  (void) hipDeviceSynchronize();
+  return static_cast<int>(g_prof.recs.size());
+}
+
+int cedr_hip_profile_get (int i, int* id, int64_t* aux, float* ms) {
+  if (i < 0 || i >= static_cast<int>(g_prof.recs.size())) return -1;
+  const ProfRec& r = g_prof.recs[i];
+  *id = r.id;
+  *aux = r.aux;
+  return static_cast<int>(hipEventElapsedTime(ms, r.a, r.b));
+}
+
+const char* cedr_hip_profile_name (int id) {
+  return (id >= 0 && id < K_COUNT) ? kKernelNames[id] : "";
 }
 
 }  // extern "C"

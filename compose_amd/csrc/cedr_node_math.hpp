@@ -1,0 +1,175 @@
+// Device-side node problems of QLT (reference cedr/cedr_local_inl.hpp and
+// cedr/cedr_qlt_inl.hpp), written for one lane = one (node, tracer). Compiled
+// with -ffp-contract=off: every operation must round exactly like the
+// reference's unfused x86-64 arithmetic because the algorithm branches on exact
+// comparisons.
+#ifndef COMPOSE_AMD_CEDR_NODE_MATH_HPP
+#define COMPOSE_AMD_CEDR_NODE_MATH_HPP
+
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+
+namespace cedr_dev {
+
+constexpr double kEps = DBL_EPSILON;
+enum : int { CONSERVE = 1, SHAPEPRESERVE = 2, CONSISTENT = 4, NONNEGATIVE = 8 };
+
+// reference cedr_kokkos.hpp:136-139: comparisons, not fmin/fmax.
+__device__ __forceinline__ double rmin (double a, double b) { return a < b ? a : b; }
+__device__ __forceinline__ double rmax (double a, double b) { return a > b ? a : b; }
+
+// ------------------------------------------------------------------ node math
+// reference cedr_local_inl.hpp:69-165 (solve_1eq_bc_qp_2d) with a = (1, 1).
+// Multiplications and divisions by the constant 1 are dropped: they are exact,
+// so every remaining operation sees the same operands in the same order.
+// w_i = 1/rhom_i and q_i = a_i/w_i = 1/w_i depend only on the node, not on the
+// tracer, so the caller computes them once per node and passes them in.
+__device__ void qp_2d (const double w0, const double w1, const double q0, const double q1,
+                       const double b,
+                       const double lo0, const double lo1, const double hi0, const double hi1,
+                       const double y0, const double y1, double& x0, double& x1,
+                       const bool clip, const bool early_exit_on_tol) {
+  if (early_exit_on_tol) {
+    // calc_r_tol (:14-18) and check_lu (:23-41)
+    double ab = fabs(b);
+    ab = rmax(ab, fabs(y0));
+    ab = rmax(ab, fabs(y1));
+    const double r_tol = 1e1*kEps*fabs(ab);
+    double r = -b;
+    r += lo0; r += lo1;
+    if ( ! (fabs(r) <= r_tol)) {
+      if (r > 0) { x0 = lo0; x1 = lo1; return; }
+      r = -b;
+      r += hi0; r += hi1;
+      if ( ! (fabs(r) <= r_tol) && r < 0) { x0 = hi0; x1 = hi1; return; }
+    }
+  }
+  {
+    double qmass = 0;
+    qmass += q0; qmass += q1;
+    double dm = b;
+    dm -= y0; dm -= y1;
+    const double lambda = dm/qmass;
+    x0 = y0 + lambda*q0;
+    if ( ! (x0 < lo0 || x0 > hi0)) {
+      x1 = y1 + lambda*q1;
+      if ( ! (x1 < lo1 || x1 > hi1)) return;
+    }
+  }
+  // Line a'x = b as base + alpha*dir, dir = (-1, 1); intersect the box edges.
+  const double base = 0.5*b;
+  double al[4];
+  al[0] = lo1 - base;      // bottom
+  al[1] = -(hi0 - base);   // right
+  al[2] = hi1 - base;      // top
+  al[3] = -(lo0 - base);   // left
+  double mn = al[0], mx = al[0];
+  int imin = 0, imax = 0;
+#pragma unroll
+  for (int i = 1; i < 4; ++i) {
+    if (al[i] < mn) { mn = al[i]; imin = i; }
+    if (al[i] > mx) { mx = al[i]; imax = i; }
+  }
+  int m0 = -1, m1 = -1;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    if (i != imin && i != imax) {
+      if (m0 < 0) m0 = i; else if (m1 < 0) m1 = i;
+    }
+  const double a0 = m0 == 0 ? al[0] : m0 == 1 ? al[1] : m0 == 2 ? al[2] : al[3];
+  const double a1 = m1 == 0 ? al[0] : m1 == 1 ? al[1] : m1 == 2 ? al[2] : al[3];
+  double obj0, obj1;
+  {
+    const double t0 = base - a0, t1 = base + a0;
+    const double d0 = y0 - t0, d1 = y1 - t1;
+    obj0 = 0; obj0 += w0*(d0*d0); obj0 += w1*(d1*d1);
+  }
+  {
+    const double t0 = base - a1, t1 = base + a1;
+    const double d0 = y0 - t0, d1 = y1 - t1;
+    obj1 = 0; obj1 += w0*(d0*d0); obj1 += w1*(d1*d1);
+  }
+  const int ai = obj0 <= obj1 ? m0 : m1;
+  if (ai == 0 || ai == 2) {
+    x1 = ai == 0 ? lo1 : hi1;
+    x0 = b - x1;
+    if (clip) x0 = rmin(hi0, rmax(lo0, x0));
+  } else {
+    x0 = ai == 1 ? hi0 : lo0;
+    x1 = b - x0;
+    if (clip) x1 = rmin(hi1, rmax(lo1, x1));
+  }
+}
+
+// reference cedr_qlt_inl.hpp:69-99 (r2l_nl_adjust_bounds)
+__device__ void adjust_bounds (double& b0, double& b1, const double rh0, const double rh1,
+                               const double extra) {
+  const double q0 = b0/rh0, q1 = b1/rh1;
+  if (extra < 0) {
+    const bool first = q0 >= q1;  // i0 = 0 if first
+    const double gap = first ? (q1 - q0)*rh0 : (q0 - q1)*rh1;
+    if (gap <= extra) { if (first) b0 += extra; else b1 += extra; return; }
+  } else {
+    const bool first = q0 <= q1;
+    const double gap = first ? (q1 - q0)*rh0 : (q0 - q1)*rh1;
+    if (gap >= extra) { if (first) b0 += extra; else b1 += extra; return; }
+  }
+  const double tot = b0 + b1 + extra;
+  const double rtot = rh0 + rh1;
+  const double qt = tot/rtot;
+  b0 = qt*rh0;
+  b1 = qt*rh1;
+}
+
+// reference cedr_qlt_inl.hpp:120-173 (mass form of the node problem)
+struct KidRho { double rh, w, q; };  // rhom, 1/rhom, 1/(1/rhom) of a kid
+
+__device__ void node_problem_mass (const double p_lo, const double p_orig, const double p_hi,
+                                   const double Qm,
+                                   const KidRho r0, double lo0, const double or0, double hi0,
+                                   const KidRho r1, double lo1, const double or1, double hi1,
+                                   double& x0, double& x1, const bool prefer) {
+  const double rh0 = r0.rh, rh1 = r1.rh;
+  const bool below = Qm < p_lo, above = Qm > p_hi;
+  if (below || above) {
+    const double tol = 10*kEps;
+    const double disc = below ? p_lo - Qm : Qm - p_hi;
+    if (disc > tol*(p_hi - p_lo)) {
+      if (below) adjust_bounds(lo0, lo1, rh0, rh1, Qm - p_lo);
+      else       adjust_bounds(hi0, hi1, rh0, rh1, Qm - p_hi);
+    }
+  } else if (Qm == p_orig && or0 >= lo0 && or0 <= hi0 && or1 >= lo1 && or1 <= hi1) {
+    x0 = or0;
+    x1 = or1;
+    return;
+  }
+  x0 = or0;
+  x1 = or1;
+  qp_2d(r0.w, r1.w, r0.q, r1.q, Qm, lo0, lo1, hi0, hi1, or0, or1, x0, x1, ! prefer, ! prefer);
+}
+
+// reference cedr_qlt_inl.hpp:175-203 (dispatch on problem type)
+__device__ void solve_node (const int pt, const double rh, const double p_lo,
+                            const double p_orig, const double p_hi, const double Qm,
+                            const KidRho r0, const double lo0, const double or0, const double hi0,
+                            const KidRho r1, const double lo1, const double or1, const double hi1,
+                            double& x0, double& x1, const bool prefer) {
+  if ((pt & CONSISTENT) && ! (pt & SHAPEPRESERVE)) {
+    node_problem_mass(p_lo*rh, p_orig, p_hi*rh, Qm,
+                      r0, lo0*r0.rh, or0, hi0*r0.rh, r1, lo1*r1.rh, or1, hi1*r1.rh, x0, x1, prefer);
+  } else if (pt & NONNEGATIVE) {
+    // solve_1eq_nonneg(2, ones, Qm, y, x, w, least_squares), cedr_local_inl.hpp:309-330
+    x0 = or0;
+    x1 = or1;
+    if (Qm < 0) return;
+    qp_2d(r0.w, r1.w, r0.q, r1.q, Qm, 0.0, 0.0, Qm, Qm, or0, or1, x0, x1, true, true);
+  } else {
+    node_problem_mass(p_lo, p_orig, p_hi, Qm, r0, lo0, or0, hi0, r1, lo1, or1, hi1,
+                      x0, x1, prefer);
+  }
+}
+
+}  // namespace cedr_dev
+
+#endif

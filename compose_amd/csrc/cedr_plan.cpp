@@ -100,6 +100,7 @@ struct Builder {
     if ( ! internals.empty()) { st.lvlptr.push_back(tile.nint); ++tile.nlvl; }
     st.max_nodes = std::max(st.max_nodes, tile.nleaf + tile.nint);
     st.max_nint = std::max(st.max_nint, tile.nint);
+    st.max_nleaf = std::max(st.max_nleaf, tile.nleaf);
     st.tiles.push_back(tile);
     pending.push_back(std::make_pair(r, tile.out));
   }
@@ -139,7 +140,8 @@ struct Builder {
 Plan build (const tree::FlatTree& t, int32_t my_rank, int32_t nranks,
             const std::vector<int32_t>& leaf_slot, const Options& opt) {
   const int32_t nn = t.size();
-  cedr_throw_if(opt.max_tile_leaves < 2, "max_tile_leaves must be >= 2");
+  cedr_throw_if(opt.max_tile_leaves < 2 || opt.max_tile_leaves > 256,
+                "max_tile_leaves must be in [2, 256]");
   Plan p;
   p.my_rank = my_rank;
   p.nranks = nranks;

@@ -45,6 +45,7 @@ struct Stage {
   std::vector<int32_t> lvlptr;  // per tile: nlvl+1 prefix offsets over its internal nodes
   int32_t max_nodes = 0;        // max over tiles of nleaf + nint
   int32_t max_nint = 0;
+  int32_t max_nleaf = 0;        // max over tiles of nleaf
 };
 
 struct Plan {
@@ -66,7 +67,7 @@ struct Plan {
 };
 
 struct Options {
-  int32_t max_tile_leaves = 256;  // inputs per tile (bounded by the kernels' LDS use)
+  int32_t max_tile_leaves = 128;  // inputs per tile (bounded by the kernels' LDS use)
 };
 
 // 'leaf_slot[n]' gives, for every tree node n that is a leaf owned by my_rank,

@@ -38,11 +38,11 @@ typedef struct {
   int32_t in0, nleaf, out, nint, kids_off, lvl_off, nlvl, pad;
 } cedr_hip_tile;
 
-/* One stage: tiles that are swept by one kernel launch. Arrays are device
- * memory. kids: 2 local node ids per internal node; lvlptr: per tile nlvl+1
+/* One stage: tiles that are swept by one kernel launch (max_nleaf <= 256).
+ * Arrays are device memory. kids: 2 local node ids per internal node; lvlptr: per tile nlvl+1
  * offsets. */
 typedef struct {
-  int32_t ntiles, max_nodes, max_nint, pad;
+  int32_t ntiles, max_nodes, max_nint, max_nleaf;
   const cedr_hip_tile* tiles;
   const uint16_t* kids;
   const int32_t* lvlptr;
@@ -133,6 +133,16 @@ int cedr_hip_caas_finish_local(int32_t nt, int32_t n, double* d, const double* r
                                cedr_stream_t stream);
 /* Bulk CAAS::DeviceOp::set_Qm / get_Qm (cedr_caas_inl.hpp:22-42) are plain
  * copies into/out of d because the layouts coincide: use hipMemcpyAsync. */
+
+/* Optional per-launch timing with HIP events recorded on the launch stream
+ * (the analogue of the reference's COMPOSE_QLT_TIME timers, cedr_qlt.cpp:19-76).
+ * start clears earlier records; stop synchronises and returns the record count;
+ * get returns one record: kernel id, an int describing the launch (tiles or
+ * cells) and the elapsed milliseconds. */
+void cedr_hip_profile_start(void);
+int cedr_hip_profile_stop(void);
+int cedr_hip_profile_get(int i, int* id, int64_t* aux, float* ms);
+const char* cedr_hip_profile_name(int id);
 
 /* ------------------------------------------------------------------ layer O */
 /* Handles are opaque. Creation functions return NULL on failure. */
