@@ -58,7 +58,6 @@ void CAASHip::end_tracer_declarations () {  // :61-74
   cedr_throw_if(tracer_decls_->size() == 0, "#tracers is 0.");
   cedr_throw_if(o.nrhomidxs_ == 0, "#rhomidxs is 0.");
   probs_h_.assign(tracer_decls_->begin(), tracer_decls_->end());
-  m_->probs.upload(probs_h_);
   o.nt_ = static_cast<Int>(probs_h_.size());
   tracer_decls_.reset();
 }
@@ -92,6 +91,8 @@ void CAASHip::set_buffers (Real* buf1, Real* buf2) {  // :93-100
 }
 
 void CAASHip::finish_setup () {  // :102-116
+  cedr_throw_if(tracer_decls_ != nullptr, "call end_tracer_declarations first");
+  if ( ! m_->probs.size()) m_->probs.upload(probs_h_);
   if (m_->recv_sz == 0) {
     size_t s1, s2, s3;
     get_buffers_sizes(s1, s2, s3);

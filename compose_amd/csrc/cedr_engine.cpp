@@ -47,6 +47,10 @@ TreeEngine::TreeEngine (const mpi::Parallel::Ptr& p, const tree::FlatTree& t,
     }
   plan_ = plan::build(t, me, p->size(), leaf_slot, opt);
   stride_ = (static_cast<int64_t>(plan_.nslots) + 15)/16*16;
+}
+
+void TreeEngine::upload () {
+  if (uploaded_) return;
   for (const auto& st : plan_.local) {
     local_.emplace_back(new DeviceStage());
     local_.back()->upload(st);
@@ -60,10 +64,12 @@ TreeEngine::TreeEngine (const mpi::Parallel::Ptr& p, const tree::FlatTree& t,
     my_top_slots_.upload(plan_.my_top_slots);
     gather_slots_.upload(plan_.gather_slots);
   }
+  uploaded_ = true;
 }
 
 void TreeEngine::up (int32_t nfields, const uint8_t* op_dev, double* data, bool zero_init,
                      hipStream_t stream) {
+  cedr_throw_if( ! uploaded_, "TreeEngine::upload was not called");
   for (const auto& st : local_)
     cedr_k_check(cedr_hip_tree_up(&st->h, nfields, op_dev, stride_, data, zero_init, stream));
   if (top_.empty()) return;

@@ -27,6 +27,11 @@ public:
   TreeEngine(const mpi::Parallel::Ptr& p, const tree::FlatTree& t, const tree::NodeSets& ns,
              const plan::Options& opt);
 
+  // The constructor only builds the host plan; upload() puts it on the GPU
+  // (called from the owners' finish_setup). Needs a device.
+  void upload();
+  bool uploaded () const { return uploaded_; }
+
   const plan::Plan& get_plan () const { return plan_; }
   // Doubles between consecutive fields: the plan's slot count rounded up to a
   // multiple of 16 so that every field row starts on a 128-byte line.
@@ -53,6 +58,7 @@ private:
   dev::Buffer<int32_t> my_root_slots_, my_top_slots_, gather_slots_;
   dev::Buffer<double> sendbuf_, recvbuf_;
   int32_t xfields_ = 0;
+  bool uploaded_ = false;
 };
 
 }  // namespace engine

@@ -156,34 +156,6 @@ void QLTHip::end_tracer_declarations () {
   cedr_throw_if( ! mdb_, "end_tracer_declarations was already called.");
   md_.init(*mdb_);
   mdb_.reset();
-  const Int nt = get_num_tracers();
-  Impl& d = *d_;
-  d.trcr2prob.upload(md_.trcr2prob);
-  d.trcr2bl2r.upload(md_.trcr2bl2r);
-  d.trcr2br2l.upload(md_.trcr2br2l);
-  std::vector<Int> bp(nt), bl(nt), br(nt);
-  for (Int bi = 0; bi < nt; ++bi) {
-    const Int ti = md_.bidx2trcr[bi];
-    bp[bi] = md_.trcr2prob[ti]; bl[bi] = md_.trcr2bl2r[ti]; br[bi] = md_.trcr2br2l[ti];
-  }
-  d.bidx_prob.upload(bp);
-  d.bidx_l2r.upload(bl);
-  d.bidx_r2l.upload(br);
-  // Combine rule of every l2r field, cedr_qlt.cpp:375-383: sums, except that a
-  // consistent-only tracer carries min(q_min) and max(q_max).
-  const Int l2rndps = md_.prob2bl2r[MetaData::nprobtypes];
-  std::vector<uint8_t> op(l2rndps, 0);
-  for (Int ti = 0; ti < nt; ++ti) {
-    const Int pt = md_.trcr2prob[ti];
-    if ((pt & ProblemType::consistent) && ! (pt & ProblemType::shapepreserve)) {
-      op[md_.trcr2bl2r[ti]] = 1;
-      op[md_.trcr2bl2r[ti] + 2] = 2;
-    }
-  }
-  d.l2r_op.upload(op);
-  o.trcr2prob = d.trcr2prob.data();
-  o.trcr2bl2r = d.trcr2bl2r.data();
-  o.trcr2br2l = d.trcr2br2l.data();
 }
 
 // Sizes in Reals. The reference returns ndps * nslots (cedr_qlt.cpp:293-298);
@@ -204,7 +176,39 @@ void QLTHip::set_buffers (Real* buf1, Real* buf2) {
 }
 
 void QLTHip::finish_setup () {
+  cedr_throw_if(mdb_ != nullptr, "call end_tracer_declarations first");
   Impl& d = *d_;
+  if (o.l2r_data) return;  // already set up
+  eng_->upload();
+  {  // tracer tables: caller order for the DeviceOp, bulk order for the kernels
+    const Int nt = get_num_tracers();
+    d.trcr2prob.upload(md_.trcr2prob);
+    d.trcr2bl2r.upload(md_.trcr2bl2r);
+    d.trcr2br2l.upload(md_.trcr2br2l);
+    std::vector<Int> bp(nt), bl(nt), br(nt);
+    for (Int bi = 0; bi < nt; ++bi) {
+      const Int ti = md_.bidx2trcr[bi];
+      bp[bi] = md_.trcr2prob[ti]; bl[bi] = md_.trcr2bl2r[ti]; br[bi] = md_.trcr2br2l[ti];
+    }
+    d.bidx_prob.upload(bp);
+    d.bidx_l2r.upload(bl);
+    d.bidx_r2l.upload(br);
+    // Combine rule of every l2r field, cedr_qlt.cpp:375-383: sums, except that a
+    // consistent-only tracer carries min(q_min) and max(q_max).
+    const Int l2rndps = md_.prob2bl2r[MetaData::nprobtypes];
+    std::vector<uint8_t> op(l2rndps, 0);
+    for (Int ti = 0; ti < nt; ++ti) {
+      const Int pt = md_.trcr2prob[ti];
+      if ((pt & ProblemType::consistent) && ! (pt & ProblemType::shapepreserve)) {
+        op[md_.trcr2bl2r[ti]] = 1;
+        op[md_.trcr2bl2r[ti] + 2] = 2;
+      }
+    }
+    d.l2r_op.upload(op);
+    o.trcr2prob = d.trcr2prob.data();
+    o.trcr2bl2r = d.trcr2bl2r.data();
+    o.trcr2br2l = d.trcr2br2l.data();
+  }
   if ( ! d.inited) {
     size_t l2r_sz, r2l_sz;
     get_buffers_sizes(l2r_sz, r2l_sz);

@@ -1,0 +1,53 @@
+"""Spawns 2 processes (gloo) that run QLT through the product's host plan + the numpy
+plan executor, exchanging subtree roots with torch.distributed.all_gather; every rank
+checks its cells bit-for-bit against the single-rank oracle. Test infrastructure."""
+import os
+import sys
+import tempfile
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def worker(rank, world, initfile, nc, pseudorandom):
+    os.environ["CEDR_HIP_TILE_LEAVES"] = "8"
+    dist.init_process_group("gloo", init_method="file://" + initfile, rank=rank, world_size=world)
+    import compose_amd as ca
+    import common
+    import oracle_lib as o
+    import plan_exec
+    import randomized as R
+    trs = R.tracers_vector()[:12]
+    types = [t.problem_type for t in trs]
+    v = R.make_values(trs, nc, seed=99)
+    want = common.run_oracle_qlt(o, (False, False), nc, 1, types, v)
+    bad = lambda *a: 1
+    q = ca.QLT(ca.Parallel.callbacks(rank, world, bad, bad), nc, ca.Tree.make_1d(nc, world, pseudorandom, False))
+    for t in types:
+        q.declare_tracer(t, 0)
+    q.end_tracer_declarations()
+    st = plan_exec.RankState(q.plan(), q.metadata())
+    g = q.get_owned_glblcells()
+    st.set(v.rhom[g], v.Qm[:, g], v.Qm_min[:, g], v.Qm_max[:, g], v.Qm_prev[:, g])
+    st.up_local()
+    send = torch.from_numpy(st.send_records())
+    bufs = [torch.zeros_like(send) for _ in range(world)]
+    dist.all_gather(bufs, send)
+    st.recv_records([b.numpy() for b in bufs])
+    st.top_and_down()
+    ok = np.array_equal(st.get(len(g)), want[:, g])
+    t = torch.tensor([1 if ok else 0])
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    dist.barrier()
+    dist.destroy_process_group()
+    if not int(t[0]):
+        sys.exit(1)
+
+
+if __name__ == "__main__":
+    for nc, pr in ((24, False), (25, True)):
+        with tempfile.TemporaryDirectory() as d:
+            mp.spawn(worker, args=(2, os.path.join(d, "init"), nc, pr), nprocs=2, join=True)
+    print("GLOO_OK")

@@ -1,0 +1,46 @@
+"""The C-ABI library loads without a GPU and exports every symbol include/cedr_hip.h
+declares; compute entry points fail loudly (no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    src = open(os.path.join(ROOT, "include", "cedr_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = set(re.findall(r"\b(cedr_[a-zA-Z0-9_]+)\s*\(", src))
+    names -= {n for n in names if n.endswith("_fn")}  # callback typedefs
+    return sorted(names)
+
+
+def test_all_declared_symbols_are_exported(ca):
+    lib = ctypes.CDLL(ca.LIB_PATH)
+    names = declared_functions()
+    assert len(names) > 80
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+
+
+def test_binding_covers_header(ca):
+    names = set(declared_functions())
+    bound = set(ca._SIGS)
+    assert bound <= names, sorted(bound - names)
+
+
+def test_no_cpu_fallback(ca):
+    if ca.device_count() > 0:
+        pytest.skip("a GPU is present")
+    q = ca.QLT(ca.Parallel.self_(), 8, ca.Tree.make_1d(8))
+    q.declare_tracer(7, 0)
+    q.end_tracer_declarations()
+    with pytest.raises(ca.CedrError):
+        q.finish_setup()  # needs device memory: must raise, never fall back
+    c = ca.CAAS(ca.Parallel.self_(), 8)
+    c.declare_tracer(7, 0)
+    c.end_tracer_declarations()
+    with pytest.raises(ca.CedrError):
+        c.finish_setup()

@@ -1,0 +1,115 @@
+"""Host logic of the product that decides WHAT the GPU does: the tile/stage plan and
+the one-all-gather multi-rank protocol. A numpy executor (plan_exec.py, test
+infrastructure) replays the plan on the CPU with the oracle's node solver; results
+must be bit-identical to the oracle's single-rank QLT whatever the tile size, the
+rank count or the ownership pattern. The world_size-2 case also runs over real
+torch.distributed (gloo) processes."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import common
+import plan_exec
+import randomized as R
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def planning_parallel(ca, rank, size):
+    if size == 1:
+        return ca.Parallel.self_()
+    bad = lambda *a: 1  # planning never communicates
+    return ca.Parallel.callbacks(rank, size, bad, bad)
+
+
+def make_rank(ca, nc, P, r, tree_args, types, tile=None, monkeypatch=None):
+    tree = ca.Tree.make_1d(nc, P, *tree_args)
+    q = ca.QLT(planning_parallel(ca, r, P), nc, tree)
+    for t in types:
+        q.declare_tracer(t, 0)
+    q.end_tracer_declarations()
+    return q, plan_exec.RankState(q.plan(), q.metadata())
+
+
+def run_plan(ca, nc, P, tree_args, types, v, prefer=False):
+    ranks = [make_rank(ca, nc, P, r, tree_args, types) for r in range(P)]
+    for q, st in ranks:
+        st.prefer = prefer
+        g = q.get_owned_glblcells()
+        st.set(v.rhom[g], v.Qm[:, g], v.Qm_min[:, g], v.Qm_max[:, g], v.Qm_prev[:, g])
+        st.up_local()
+    allbuf = [st.send_records() for _, st in ranks]  # the all-gather
+    out = np.zeros_like(v.Qm)
+    for q, st in ranks:
+        if P > 1:
+            st.recv_records(allbuf)
+        st.top_and_down()
+        g = q.get_owned_glblcells()
+        out[:, g] = st.get(len(g))
+    return out
+
+
+@pytest.mark.parametrize("nc,P,pseudorandom,imbalanced", [
+    (1, 1, False, False), (2, 1, False, False), (37, 1, False, True), (200, 1, False, False),
+    (2, 2, False, False), (24, 2, False, False), (60, 3, False, True), (64, 8, False, False),
+    (56, 8, True, False), (40, 4, True, True)])
+def test_plan_execution_matches_oracle(ca, oracle, nc, P, pseudorandom, imbalanced, monkeypatch):
+    monkeypatch.setenv("CEDR_HIP_TILE_LEAVES", "8")  # several stages even on small trees
+    trs = R.tracers_vector()[:12]  # all six problem types, two perturbations
+    types = [t.problem_type for t in trs]
+    v = R.make_values(trs, nc, seed=nc + P)
+    want = common.run_oracle_qlt(oracle, (False, imbalanced), nc, 1, types, v)
+    got = run_plan(ca, nc, P, (pseudorandom, imbalanced), types, v)
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("tile", [2, 3, 5, 64, 256])
+def test_plan_invariants(ca, tile):
+    nc = 1000
+    tree = ca.Tree.make_1d(nc, 1, False, True)
+    pl = tree.plan(nc, 0, 1, tile)
+    assert pl["nlcl"] == nc
+    seen = np.zeros(pl["nslots"], np.int32)
+    covered = np.zeros(pl["nslots"], np.int32)
+    for st in pl["local"]:
+        for t in st["tiles"]:
+            in0, nleaf, out, nint, koff, loff, nlvl = [int(x) for x in t[:7]]
+            assert 1 <= nleaf <= tile and nint == nleaf - 1
+            covered[in0:in0 + nleaf] += 1
+            seen[out] += 1
+            kids = st["kids"][koff:koff + nint]
+            for j in range(nint):  # kids come before parents
+                assert (kids[j] < nleaf + j).all()
+            used = np.bincount(kids.ravel(), minlength=nleaf + nint)
+            assert (used[:nleaf + nint - 1] == 1).all()  # a tree: every non-root node used once
+            lp = st["lvlptr"][loff:loff + nlvl + 1]
+            assert lp[0] == 0 and lp[-1] == nint and (np.diff(lp) > 0).all()
+    assert (seen[nc:] == 1).all() and (seen[:nc] == 0).all()
+    assert (covered[:pl["root_slot"]] == 1).all() and covered[pl["root_slot"]] == 0
+    assert pl["stride"] % 16 == 0 and pl["stride"] >= pl["nslots"]
+
+
+def test_multirank_plan_shapes(ca):
+    nc, P = 64, 8
+    tree = ca.Tree.make_1d(nc, P)
+    for r in range(P):
+        pl = tree.plan(nc, r, P, 128)
+        assert pl["nlcl"] == 8 and pl["nb_max"] == 1 and pl["nmyroots"] == 1
+        gs = pl["gather_slots"]
+        assert gs.shape == (P, 1) and len(set(gs.ravel())) == P
+        assert pl["my_top_slots"][0] == gs[r, 0]
+        assert len(pl["top"]) == 1 and len(pl["top"][0]["tiles"]) == 1
+
+
+def test_gloo_two_ranks():
+    """world_size 2 over real processes: torch.distributed (gloo) all_gather carries
+    the subtree-root records between the two ranks' plan executors."""
+    env = dict(os.environ)
+    env["PYTHONPATH"] = os.pathsep.join([os.path.dirname(HERE), HERE, env.get("PYTHONPATH", "")])
+    res = subprocess.run([sys.executable, os.path.join(HERE, "mp_gloo_worker.py")], env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    assert "GLOO_OK" in res.stdout
