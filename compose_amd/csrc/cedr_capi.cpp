@@ -234,6 +234,7 @@ void* cedr_plan_create (void* tree, int ncells, int my_rank, int nranks, int max
     if (t.nkids[n] == 0 && t.rank[n] == my_rank) leaf_slot[n] = g2l.at(static_cast<Int>(t.cellidx[n]));
   plan::Options o;
   if (max_tile_leaves > 0) o.max_tile_leaves = max_tile_leaves;
+  if (max_tile_leaves < 0) { o.micro = false; if (max_tile_leaves < -1) o.max_tile_leaves = -max_tile_leaves; }
   PlanBox* b = new PlanBox();
   b->owned = plan::build(t, my_rank, nranks, leaf_slot, o);
   b->p = &b->owned;
@@ -267,6 +268,13 @@ int cedr_plan_stage_sizes (void* h, int top, int idx, int* sz) {
   if ( ! st) { g_err = "no such stage"; return -1; }
   sz[0] = static_cast<int>(st->tiles.size()); sz[1] = st->max_nodes;
   sz[2] = static_cast<int>(st->kids.size()/2); sz[3] = static_cast<int>(st->lvlptr.size());
+  sz[4] = static_cast<int>(st->micro.size());
+  return 0;
+}
+int cedr_plan_stage_micro (void* h, int top, int idx, uint16_t* micro) {
+  const plan::Stage* st = get_stage(h, top, idx);
+  if ( ! st) { g_err = "no such stage"; return -1; }
+  std::copy(st->micro.begin(), st->micro.end(), micro);
   return 0;
 }
 int cedr_plan_stage (void* h, int top, int idx, int* tiles, uint16_t* kids, int* lvlptr) {

@@ -15,7 +15,7 @@ void DeviceStage::upload (const plan::Stage& st) {
   std::vector<cedr_hip_tile> tl(st.tiles.size());
   for (size_t i = 0; i < tl.size(); ++i) {
     const plan::Tile& s = st.tiles[i];
-    tl[i] = cedr_hip_tile{s.in0, s.nleaf, s.out, s.nint, s.kids_off, s.lvl_off, s.nlvl, 0};
+    tl[i] = cedr_hip_tile{s.in0, s.nleaf, s.out, s.nint, s.kids_off, s.lvl_off, s.nlvl, s.micro_off};
   }
   tiles.upload(tl);
   kids.upload(st.kids);
@@ -27,6 +27,8 @@ void DeviceStage::upload (const plan::Stage& st) {
   h.tiles = tiles.data();
   h.kids = kids.data();
   h.lvlptr = lvlptr.data();
+  micro.upload(st.micro);
+  h.micro = st.micro.empty() ? nullptr : micro.data();
 }
 
 TreeEngine::TreeEngine (const mpi::Parallel::Ptr& p, const tree::FlatTree& t,

@@ -293,6 +293,354 @@ void qlt_down_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st,
   }
 }
 
+// ------------------------------------------------------------ micro tiles
+// First-stage tiles over real cells: lane i of a wave owns micro-subtree i of
+// the tile (<= 3 consecutive cells: a, b, c) and combines / solves it in
+// registers; only the micro-subtrees' roots and the nodes above them live in
+// LDS. That cuts the LDS footprint per cell by ~3 and removes the two largest
+// tree levels from the barrier-separated LDS phases.
+struct Micro { int start, shape, size; };
+
+__device__ __forceinline__ Micro get_micro (const cedr_hip_stage& st, const cedr_hip_tile& tile,
+                                            const int lane) {
+  Micro m{0, -1, 0};
+  if (lane < tile.nleaf) {
+    const uint32_t d = st.micro[tile.micro_off + lane];
+    m.start = d & 0xff;
+    m.shape = d >> 8;
+    m.size = m.shape == 0 ? 1 : (m.shape == 1 ? 2 : 3);
+  }
+  return m;
+}
+
+__device__ __forceinline__ double combine (const int o, const int zero_init, const double k0,
+                                           const double k1) {
+  if (o == 0) {
+    if (zero_init) { double r = 0; r += k0; r += k1; return r; }
+    return k0 + k1;
+  }
+  return o == 1 ? rmin(k0, k1) : rmax(k0, k1);
+}
+
+// Root value of a micro-subtree: shape 1 = (a,b), 2 = ((a,b),c), 3 = (a,(b,c)).
+__device__ __forceinline__ double micro_up (const int shape, const int o, const int zi,
+                                            const double a, const double b, const double c) {
+  const double t = combine(o, zi, shape == 3 ? b : a, shape == 3 ? c : b);
+  if (shape <= 0) return a;
+  if (shape == 1) return t;
+  return shape == 2 ? combine(o, zi, t, c) : combine(o, zi, a, t);
+}
+
+template <int FT>
+__global__ __launch_bounds__(kBlock)
+void tree_up_micro_kernel (const cedr_hip_stage st, const int nfields,
+                           const uint8_t* __restrict__ op, const int64_t stride,
+                           double* __restrict__ data, const int zero_init, const int pitch) {
+  extern __shared__ double lds[];
+  const cedr_hip_tile tile = st.tiles[blockIdx.x];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & (kWave - 1);
+  uint32_t* const kidsL = reinterpret_cast<uint32_t*>(lds);
+  int32_t* const lvlL = reinterpret_cast<int32_t*>(kidsL + st.max_nint);
+  double* const v = lds + (st.max_nint + 1);
+  const int nleaf = tile.nleaf;
+  const int nchunks = (nfields + FT - 1)/FT;
+  const Micro m = get_micro(st, tile, lane);
+  const double* __restrict__ src0 = data + tile.in0 + m.start;
+  constexpr int NR = FT/kNW;
+
+  auto load = [&] (const int c, double (&buf)[NR][3]) {
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      const int f = c*FT + wave + kNW*r;
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+        buf[r][k] = (f < nfields && k < m.size) ? src0[static_cast<size_t>(f)*stride + k] : 0.0;
+    }
+  };
+
+  double cur[NR][3];
+  if (static_cast<int>(blockIdx.y) < nchunks) load(blockIdx.y, cur);
+  stage_tile_meta(st, tile, kidsL, lvlL);
+  const int root = tile.nint ? nleaf + tile.nint - 1 : 0;
+  const int ff = threadIdx.x & (FT - 1);
+  double* const vf = v + ff*pitch;
+
+  for (int c = blockIdx.y; c < nchunks; c += gridDim.y) {
+    double nxt[NR][3];
+    const int cn = c + gridDim.y;
+    if (cn < nchunks) load(cn, nxt);
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      const int fr = c*FT + wave + kNW*r;
+      const int orow = fr < nfields ? op[fr] : 0;
+      const double val = micro_up(m.shape, orow, zero_init, cur[r][0], cur[r][1], cur[r][2]);
+      if (lane < nleaf) v[(wave + kNW*r)*pitch + lane] = val;
+    }
+    const int f = c*FT + ff;
+    const int o = f < nfields ? op[f] : 0;
+    __syncthreads();
+    for (int lv = 0; lv < tile.nlvl; ++lv) {
+      const int a = lvlL[lv];
+      const int nitems = (lvlL[lv+1] - a) << Log2<FT>::value;
+      for (int q = threadIdx.x; q < nitems; q += kBlock) {
+        const int j = a + (q >> Log2<FT>::value);
+        const uint32_t kk = kidsL[j];
+        vf[nleaf + j] = combine(o, zero_init, vf[kk & 0xffff], vf[kk >> 16]);
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x < FT && f < nfields)
+      data[static_cast<size_t>(f)*stride + tile.out] = vf[root];
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < NR; ++r)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) cur[r][k] = nxt[r][k];
+  }
+}
+
+// Root -> leaves over micro tiles. 4 tracers per chunk, one per wave for the
+// register part; the LDS part spreads (node, tracer) items over all threads.
+#ifndef CEDR_MICRO_PREFETCH
+# define CEDR_MICRO_PREFETCH 0
+#endif
+#ifndef CEDR_MICRO_WAVES
+# define CEDR_MICRO_WAVES 4
+#endif
+__global__ __launch_bounds__(kBlock, CEDR_MICRO_WAVES)
+void qlt_down_micro_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st,
+                            double* __restrict__ l2r, double* __restrict__ r2l, const int pitch) {
+  constexpr int TT = kNW;
+  extern __shared__ double lds[];
+  const cedr_hip_tile tile = st.tiles[blockIdx.x];
+  const int MN = st.max_nodes;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & (kWave - 1);
+  uint32_t* const kidsL = reinterpret_cast<uint32_t*>(lds);
+  int32_t* const lvlL = reinterpret_cast<int32_t*>(kidsL + st.max_nint);
+  double* const rho = lds + (st.max_nint + 1);
+  double* const rw = rho + MN;
+  double* const rq = rw + MN;
+  double* const recs = rq + MN;
+  const int nleaf = tile.nleaf;
+  const int64_t S = L.stride;
+  const bool prefer = L.prefer_mass_con != 0;
+  const int nt = L.nt;
+  const int nchunks = (nt + TT - 1)/TT;
+  const Micro m = get_micro(st, tile, lane);
+  const int cell0 = tile.in0 + m.start;
+
+  // Input records {lo, orig, hi} of this lane's cells for tracer bi (see
+  // qlt_down_kernel for which l2r fields they are).
+  auto load = [&] (const int bi, double (&buf)[3][3]) {
+    bool sp = false;
+    int field = 0;
+    if (bi < nt) {
+      const int pt = L.bidx_prob[bi];
+      sp = (pt & SHAPEPRESERVE) != 0;
+      field = L.bidx_l2r[bi] + (sp ? 0 : ((pt & CONSISTENT) ? 1 : 0));
+    }
+    const double* __restrict__ s0 = l2r + static_cast<size_t>(field)*S + cell0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const bool in = bi < nt && k < m.size;
+      if (sp) {
+        buf[k][0] = in ? s0[k] : 0.0;
+        buf[k][1] = in ? s0[S + k] : 0.0;
+        buf[k][2] = in ? s0[2*S + k] : 0.0;
+      } else {
+        buf[k][0] = 0.0;
+        buf[k][1] = in ? s0[k] : 0.0;
+        buf[k][2] = 0.0;
+      }
+    }
+  };
+
+  double cur[3][3];  // [cell a,b,c][lo, orig, hi]
+  load(blockIdx.y*TT + wave, cur);
+
+  // Densities of this lane's micro-subtree: cells a, b, c, the inner pair t and
+  // the root, with 1/rhom and 1/(1/rhom) of everything that can be a kid.
+  double rr;
+  KidRho ka, kb, kc, kt;
+  {
+    const double* __restrict__ src = l2r + cell0;
+    ka.rh = m.size > 0 ? src[0] : 1.0;
+    kb.rh = m.size > 1 ? src[1] : 1.0;
+    kc.rh = m.size > 2 ? src[2] : 1.0;
+    kt.rh = (m.shape == 3 ? kb.rh : ka.rh) + (m.shape == 3 ? kc.rh : kb.rh);
+    rr = m.shape <= 0 ? ka.rh : (m.shape == 1 ? kt.rh : (m.shape == 2 ? kt.rh + kc.rh : ka.rh + kt.rh));
+    ka.w = 1.0/ka.rh; ka.q = 1.0/ka.w;
+    kb.w = 1.0/kb.rh; kb.q = 1.0/kb.w;
+    kc.w = 1.0/kc.rh; kc.q = 1.0/kc.w;
+    kt.w = 1.0/kt.rh; kt.q = 1.0/kt.w;
+    if (wave == 0 && lane < nleaf) rho[lane] = rr;
+  }
+  stage_tile_meta(st, tile, kidsL, lvlL);
+  __syncthreads();
+  for (int lv = 0; lv < tile.nlvl; ++lv) {
+    const int a = lvlL[lv], b = lvlL[lv+1];
+    for (int j = a + threadIdx.x; j < b; j += kBlock) {
+      const uint32_t kk = kidsL[j];
+      rho[nleaf + j] = rho[kk & 0xffff] + rho[kk >> 16];
+    }
+    __syncthreads();
+  }
+  for (int i = threadIdx.x; i < nleaf + tile.nint; i += kBlock) {
+    const double w = 1.0/rho[i];
+    rw[i] = w;
+    rq[i] = 1.0/w;
+  }
+  const int root = tile.nint ? nleaf + tile.nint - 1 : 0;
+  const int tt = threadIdx.x & (TT - 1);  // tracer of this thread in the LDS phases
+  double* const R = recs + tt*pitch;      // its record row
+  double* const Rw = recs + wave*pitch;   // record row of this wave's tracer
+
+  for (int c = blockIdx.y; c < nchunks; c += gridDim.y) {
+#if CEDR_MICRO_PREFETCH
+    double nxt[3][3];
+    const int cn = c + gridDim.y;
+    if (cn < nchunks) load(cn*TT + wave, nxt);
+#else
+    if (c != static_cast<int>(blockIdx.y)) load(c*TT + wave, cur);
+#endif
+
+    // ---- this wave's tracer: micro-subtree sums in registers, root record to LDS
+    const int biw = c*TT + wave;
+    const bool livew = biw < nt;
+    const int ptw = livew ? L.bidx_prob[biw] : (SHAPEPRESERVE | CONSISTENT);
+    const bool spw = (ptw & SHAPEPRESERVE) != 0;
+    const bool t_onlyw = (ptw & CONSISTENT) && ! spw;
+    double T[3], RR[3];  // inner pair t and micro root: {lo, orig, hi} sums
+#pragma unroll
+    for (int f = 0; f < 3; ++f) {
+      const double u = m.shape == 3 ? cur[1][f] : cur[0][f];
+      const double vv = m.shape == 3 ? cur[2][f] : cur[1][f];
+      T[f] = u + vv;
+      RR[f] = m.shape <= 0 ? cur[0][f] :
+        (m.shape == 1 ? T[f] : (m.shape == 2 ? T[f] + cur[2][f] : cur[0][f] + T[f]));
+    }
+    if (lane < nleaf) { Rw[4*lane] = RR[0]; Rw[4*lane+1] = RR[1]; Rw[4*lane+2] = RR[2]; }
+
+    // ---- the LDS phases' tracer of this thread
+    const int bi = c*TT + tt;
+    const bool live = bi < nt;
+    const int pt = live ? L.bidx_prob[bi] : (SHAPEPRESERVE | CONSISTENT);
+    const int rb = live ? L.bidx_r2l[bi] : 0;
+    const bool sp = (pt & SHAPEPRESERVE) != 0;
+    const bool t_only = (pt & CONSISTENT) && ! sp;
+    double Xroot = 0, qlo = 0, qhi = 0;
+    if (live) {
+      Xroot = r2l[static_cast<size_t>(rb)*S + tile.out];
+      if (t_only) {
+        qlo = r2l[static_cast<size_t>(rb + 1)*S + tile.out];
+        qhi = r2l[static_cast<size_t>(rb + 2)*S + tile.out];
+      }
+    }
+    __syncthreads();  // also orders rho/rw/rq before their first use
+    for (int lv = 0; lv < tile.nlvl; ++lv) {
+      const int a = lvlL[lv];
+      const int nitems = (lvlL[lv+1] - a) << Log2<TT>::value;
+      for (int q = threadIdx.x; q < nitems; q += kBlock) {
+        const int j = a + (q >> Log2<TT>::value);
+        const uint32_t kk = kidsL[j];
+        const double* K0 = R + 4*(kk & 0xffff);
+        const double* K1 = R + 4*(kk >> 16);
+        double* me = R + 4*(nleaf + j);
+        if (sp) { me[0] = K0[0] + K1[0]; me[2] = K0[2] + K1[2]; }
+        me[1] = K0[1] + K1[1];
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x < TT) R[4*root + 3] = Xroot;
+    __syncthreads();
+    for (int lv = tile.nlvl - 1; lv >= 0; --lv) {
+      const int a = lvlL[lv];
+      const int nitems = (lvlL[lv+1] - a) << Log2<TT>::value;
+      for (int q = threadIdx.x; q < nitems; q += kBlock) {
+        const int j = a + (q >> Log2<TT>::value);
+        const uint32_t kk = kidsL[j];
+        const int c0 = kk & 0xffff, c1 = kk >> 16, me = nleaf + j;
+        const KidRho r0{rho[c0], rw[c0], rq[c0]}, r1{rho[c1], rw[c1], rq[c1]};
+        const double* P = R + 4*me;
+        double* K0 = R + 4*c0;
+        double* K1 = R + 4*c1;
+        double x0, x1;
+        if (t_only)
+          solve_node(pt, rho[me], qlo, P[1], qhi, P[3], r0, qlo, K0[1], qhi,
+                     r1, qlo, K1[1], qhi, x0, x1, prefer);
+        else
+          solve_node(pt, rho[me], P[0], P[1], P[2], P[3], r0, K0[0], K0[1], K0[2],
+                     r1, K1[0], K1[1], K1[2], x0, x1, prefer);
+        K0[3] = x0;
+        K1[3] = x1;
+      }
+      __syncthreads();
+    }
+
+    // ---- this wave's tracer again: node problems of the micro-subtree in
+    // registers, then the cells' masses to HBM.
+    if (livew && lane < nleaf) {
+      const int rbw = L.bidx_r2l[biw];
+      double qlw = 0, qhw = 0;
+      if (t_onlyw) {
+        qlw = r2l[static_cast<size_t>(rbw + 1)*S + tile.out];
+        qhw = r2l[static_cast<size_t>(rbw + 2)*S + tile.out];
+      }
+      const double Xr = Rw[4*lane + 3];
+      double Xa = Xr, Xb = 0, Xc = 0, Xt = 0;
+      // bounds seen by the node problems: the cells' own, or the global q bounds
+      auto lo = [&] (const double x) { return t_onlyw ? qlw : x; };
+      auto hi = [&] (const double x) { return t_onlyw ? qhw : x; };
+      if (m.shape >= 1) {
+        // root -> (k0, k1): shape 1 (a,b); 2 (t,c); 3 (a,t)
+        const bool s2 = m.shape == 2, s1 = m.shape == 1;
+        const KidRho r0 = s2 ? kt : ka;
+        const KidRho r1 = s1 ? kb : (s2 ? kc : kt);
+        const double l0 = s2 ? T[0] : cur[0][0], o0 = s2 ? T[1] : cur[0][1], h0 = s2 ? T[2] : cur[0][2];
+        const double l1 = s1 ? cur[1][0] : (s2 ? cur[2][0] : T[0]);
+        const double o1 = s1 ? cur[1][1] : (s2 ? cur[2][1] : T[1]);
+        const double h1 = s1 ? cur[1][2] : (s2 ? cur[2][2] : T[2]);
+        double x0, x1;
+        solve_node(ptw, rr, lo(RR[0]), RR[1], hi(RR[2]), Xr, r0, lo(l0), o0, hi(h0),
+                   r1, lo(l1), o1, hi(h1), x0, x1, prefer);
+        if (s2) Xt = x0; else Xa = x0;
+        if (s1) Xb = x1; else if (s2) Xc = x1; else Xt = x1;
+      }
+      if (m.shape >= 2) {
+        // t -> shape 2 (a,b); 3 (b,c)
+        const bool s2 = m.shape == 2;
+        const KidRho r0 = s2 ? ka : kb;
+        const KidRho r1 = s2 ? kb : kc;
+        const int i0 = s2 ? 0 : 1;
+        double x0, x1;
+        solve_node(ptw, kt.rh, lo(T[0]), T[1], hi(T[2]), Xt,
+                   r0, lo(s2 ? cur[0][0] : cur[1][0]), s2 ? cur[0][1] : cur[1][1],
+                   hi(s2 ? cur[0][2] : cur[1][2]),
+                   r1, lo(s2 ? cur[1][0] : cur[2][0]), s2 ? cur[1][1] : cur[2][1],
+                   hi(s2 ? cur[1][2] : cur[2][2]), x0, x1, prefer);
+        (void) i0;
+        if (s2) { Xa = x0; Xb = x1; } else { Xb = x0; Xc = x1; }
+      }
+      double* __restrict__ dst = r2l + static_cast<size_t>(rbw)*S + cell0;
+      dst[0] = Xa;
+      if (m.size > 1) dst[1] = Xb;
+      if (m.size > 2) dst[2] = Xc;
+      if (t_onlyw) {
+        double* __restrict__ l0p = l2r + static_cast<size_t>(L.bidx_l2r[biw])*S + cell0;
+        for (int k = 0; k < m.size; ++k) {
+          dst[S + k] = qlw; dst[2*S + k] = qhw; l0p[k] = qlw; l0p[2*S + k] = qhw;
+        }
+      }
+    }
+#if CEDR_MICRO_PREFETCH
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+      for (int f = 0; f < 3; ++f) cur[k][f] = nxt[k][f];
+#endif
+  }
+}
+
 // reference cedr_qlt.cpp:453-473 (root_compute), one thread per bulk index.
 __global__ void qlt_root_kernel (const cedr_hip_qlt_layout L, const int root_slot,
                                  const double* __restrict__ l2r, double* __restrict__ r2l) {
@@ -643,7 +991,13 @@ int cedr_hip_tree_up (const cedr_hip_stage* st, int32_t nfields, const uint8_t* 
   const size_t lds = sizeof(double)*(meta_doubles(st) + static_cast<size_t>(kUpFT)*pitch);
   if (lds > 160*1024) return static_cast<int>(hipErrorInvalidValue);
   const dim3 grid(st->ntiles, chunk_split(st->ntiles, (nfields + kUpFT - 1)/kUpFT));
-  if (st->max_nleaf <= 128) {
+  if (st->micro) {
+    if (st->max_nleaf > kWave) return static_cast<int>(hipErrorInvalidValue);
+    int e = set_lds_limit(tree_up_micro_kernel<kUpFT>, lds);
+    if (e) return e;
+    hipLaunchKernelGGL((tree_up_micro_kernel<kUpFT>), grid, dim3(kBlock), lds, stream,
+                       *st, nfields, op, stride, data, zero_init, pitch);
+  } else if (st->max_nleaf <= 128) {
     int e = set_lds_limit(tree_up_kernel<kUpFT, 2>, lds);
     if (e) return e;
     hipLaunchKernelGGL((tree_up_kernel<kUpFT, 2>), grid, dim3(kBlock), lds, stream,
@@ -664,6 +1018,16 @@ int cedr_hip_qlt_down (const cedr_hip_qlt_layout* lay, const cedr_hip_stage* st,
   if (st->max_nleaf > 256) return static_cast<int>(hipErrorInvalidValue);
   const size_t mn = st->max_nodes;
   const int pitch = pitch_for(4*st->max_nodes);
+  if (st->micro) {
+    if (st->max_nleaf > kWave) return static_cast<int>(hipErrorInvalidValue);
+    const size_t ldsm = sizeof(double)*(meta_doubles(st) + 3*mn + static_cast<size_t>(kNW)*pitch);
+    int e = set_lds_limit(qlt_down_micro_kernel, ldsm);
+    if (e) return e;
+    const dim3 gridm(st->ntiles, chunk_split(st->ntiles, (lay->nt + kNW - 1)/kNW));
+    hipLaunchKernelGGL(qlt_down_micro_kernel, gridm, dim3(kBlock), ldsm, stream,
+                       *lay, *st, l2r, r2l, pitch);
+    return launch_status();
+  }
   const size_t lds = sizeof(double)*(meta_doubles(st) + 3*mn + static_cast<size_t>(kDownTT)*pitch);
   if (lds > 160*1024) return static_cast<int>(hipErrorInvalidValue);
   const dim3 grid(st->ntiles, chunk_split(st->ntiles, (lay->nt + kDownTT - 1)/kDownTT));

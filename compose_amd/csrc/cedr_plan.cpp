@@ -16,7 +16,13 @@ struct Builder {
   std::vector<int32_t> cnt;    // scratch: # current inputs below a node
   std::vector<int32_t> lid;    // scratch: local id inside the tile being built
   std::vector<int32_t> llvl;   // scratch: local level inside the tile being built
+  std::vector<int32_t> nleaves; // # real leaves below a node (filled by the caller)
+  bool micro_mode = false;     // inputs are micro-subtrees (<= 3 leaves) instead of slots
   int32_t next_slot;
+
+  bool is_input (const int32_t n) const {
+    return micro_mode ? nleaves[n] <= 3 : slot[n] >= 0;
+  }
 
   Builder (const tree::FlatTree& t_, const Options& o)
     : t(t_), opt(o), slot(t_.size(), -1), cnt(t_.size(), 0), lid(t_.size(), -1),
@@ -29,7 +35,7 @@ struct Builder {
     while ( ! st.empty()) {
       auto& top = st.back();
       const int32_t n = top.first;
-      if (slot[n] >= 0) { cnt[n] = 1; st.pop_back(); continue; }
+      if (is_input(n)) { cnt[n] = 1; st.pop_back(); continue; }
       if (top.second < 2) {
         const int32_t k = t.kid(n, top.second++);
         st.push_back(std::make_pair(k, 0));
@@ -44,7 +50,8 @@ struct Builder {
   // slot >= 0 met by the DFS, in DFS order; their slots must be consecutive.
   void build_tile (Stage& st, const int32_t r) {
     Tile tile;
-    tile.pad = 0;
+    tile.micro_off = micro_mode ? static_cast<int32_t>(st.micro.size()) : 0;
+    int32_t nreal = 0;  // real leaves seen so far (micro mode)
     tile.kids_off = static_cast<int32_t>(st.kids.size()/2);
     tile.lvl_off = static_cast<int32_t>(st.lvlptr.size());
     tile.out = next_slot++;
@@ -56,11 +63,34 @@ struct Builder {
       while ( ! stack.empty()) {
         auto& top = stack.back();
         const int32_t n = top.first;
-        if (slot[n] >= 0) {
-          if (nleaf == 0) in0 = slot[n];
-          cedr_throw_if(slot[n] != in0 + nleaf,
-                        "The local cell order does not keep each owned subtree's cells "
-                        "contiguous; this ordering is not supported yet.");
+        if (is_input(n)) {
+          if (micro_mode) {
+            // Leaves of the micro-subtree in DFS order, and its shape.
+            int32_t lv[3], nl = 0;
+            int32_t shape = 0;
+            if (t.nkids[n] == 0) lv[nl++] = n;
+            else {
+              const int32_t a = t.kid0[n], b = t.kid1[n];
+              if (t.nkids[a] == 0) lv[nl++] = a; else { lv[nl++] = t.kid0[a]; lv[nl++] = t.kid1[a]; }
+              if (t.nkids[b] == 0) lv[nl++] = b; else { lv[nl++] = t.kid0[b]; lv[nl++] = t.kid1[b]; }
+              shape = nl == 2 ? 1 : (t.nkids[a] ? 2 : 3);
+            }
+            for (int32_t i = 0; i < nl; ++i) {
+              cedr_throw_if(slot[lv[i]] < 0, "micro-subtree leaf without a slot");
+              if (nleaf == 0 && i == 0) in0 = slot[lv[0]];
+              cedr_throw_if(slot[lv[i]] != in0 + nreal + i,
+                            "The local cell order does not keep each owned subtree's cells "
+                            "contiguous; this ordering is not supported yet.");
+            }
+            cedr_throw_if(nreal > 255, "micro tile spans more than 255 leaves");
+            st.micro.push_back(static_cast<uint16_t>(nreal | (shape << 8)));
+            nreal += nl;
+          } else {
+            if (nleaf == 0) in0 = slot[n];
+            cedr_throw_if(slot[n] != in0 + nleaf,
+                          "The local cell order does not keep each owned subtree's cells "
+                          "contiguous; this ordering is not supported yet.");
+          }
           lid[n] = nleaf++;
           llvl[n] = 0;
           stack.pop_back();
@@ -108,8 +138,12 @@ struct Builder {
   std::vector<std::pair<int32_t,int32_t> > pending;  // (tile root, out slot) of the stage
 
   // Reduce every root in 'roots' to a single input slot, appending stages.
-  void tile_forest (const std::vector<int32_t>& roots, std::vector<Stage>& stages) {
+  void tile_forest (const std::vector<int32_t>& roots, std::vector<Stage>& stages,
+                    const bool micro_first) {
+    bool first = true;
     for (;;) {
+      micro_mode = micro_first && first;
+      first = false;
       std::vector<int32_t> active;
       for (const int32_t r : roots) if (slot[r] < 0) active.push_back(r);
       if (active.empty()) break;
@@ -120,7 +154,7 @@ struct Builder {
       while ( ! stack.empty()) {
         const int32_t n = stack.back();
         stack.pop_back();
-        if (slot[n] >= 0 || cnt[n] <= opt.max_tile_leaves) {
+        if (is_input(n) || cnt[n] <= (micro_mode ? 64 : opt.max_tile_leaves)) {
           // An input hanging directly off a too-large node becomes a 1-input
           // tile (a copy) so that the next stage's inputs stay contiguous.
           build_tile(st, n);
@@ -132,6 +166,7 @@ struct Builder {
       for (const auto& p : pending) slot[p.first] = p.second;
       stages.push_back(std::move(st));
     }
+    micro_mode = false;
   }
 };
 
@@ -175,6 +210,9 @@ Plan build (const tree::FlatTree& t, int32_t my_rank, int32_t nranks,
   }
 
   Builder b(t, opt);
+  b.nleaves.assign(nn, 1);
+  for (const Int n : tree::post_order(t))
+    if (t.nkids[n]) b.nleaves[n] = b.nleaves[t.kid0[n]] + b.nleaves[t.kid1[n]];
   for (int32_t n = 0; n < nn; ++n)
     if (t.nkids[n] == 0 && t.rank[n] == my_rank) {
       cedr_throw_if(leaf_slot[n] < 0, "owned leaf without a local index");
@@ -185,7 +223,7 @@ Plan build (const tree::FlatTree& t, int32_t my_rank, int32_t nranks,
 
   std::vector<int32_t> my_roots;
   for (const int32_t r : broots) if (own[r] == my_rank) my_roots.push_back(r);
-  b.tile_forest(my_roots, p.local);
+  b.tile_forest(my_roots, p.local, opt.micro);
   for (const int32_t r : my_roots) p.my_root_slots.push_back(b.slot[r]);
 
   if (broots.size() > 1) {
@@ -200,7 +238,7 @@ Plan build (const tree::FlatTree& t, int32_t my_rank, int32_t nranks,
       p.gather_slots[static_cast<size_t>(own[r])*p.nb_max + per_rank[own[r]]++] = ts;
       if (own[r] == my_rank) p.my_top_slots.push_back(ts);
     }
-    b.tile_forest(std::vector<int32_t>(1, 0), p.top);
+    b.tile_forest(std::vector<int32_t>(1, 0), p.top, false);
   }
   p.root_slot = b.slot[0];
   p.nslots = b.next_slot;

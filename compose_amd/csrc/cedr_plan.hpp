@@ -28,15 +28,21 @@ namespace plan {
 // Local node numbering inside a tile: inputs 0..nleaf-1 in slot order, then
 // internal nodes nleaf..nleaf+nint-1 ordered by local level (kids before
 // parents); the tile root is the last node (or input 0 if nint == 0).
+//
+// MICRO tiles (first stage over real cells only): the inputs of the tile's LDS
+// tree are not single slots but "micro-subtrees" of at most 3 consecutive
+// leaves, one per lane, combined/solved in registers. Then nleaf counts the
+// micro-subtrees (<= 64), micro_off points at their descriptors in
+// Stage::micro, and in0 is the slot of the first leaf of the first micro-subtree.
 struct Tile {
   int32_t in0;       // first input slot
-  int32_t nleaf;     // number of input slots
+  int32_t nleaf;     // number of inputs of the LDS tree (slots, or micro-subtrees)
   int32_t out;       // slot the tile root's record is written to / read from
   int32_t nint;      // number of internal nodes
   int32_t kids_off;  // offset of this tile's first internal node in Stage::kids (pairs)
   int32_t lvl_off;   // offset into Stage::lvlptr
   int32_t nlvl;      // number of local levels of internal nodes
-  int32_t pad;
+  int32_t micro_off; // micro tiles: offset into Stage::micro; else 0
 };
 
 struct Stage {
@@ -46,6 +52,10 @@ struct Stage {
   int32_t max_nodes = 0;        // max over tiles of nleaf + nint
   int32_t max_nint = 0;
   int32_t max_nleaf = 0;        // max over tiles of nleaf
+  // Micro tiles only (empty otherwise): per micro-subtree, first leaf relative
+  // to the tile's in0 (low byte) and shape (high byte): 0 = one leaf a,
+  // 1 = (a,b), 2 = ((a,b),c), 3 = (a,(b,c)).
+  std::vector<uint16_t> micro;
 };
 
 struct Plan {
@@ -68,6 +78,7 @@ struct Plan {
 
 struct Options {
   int32_t max_tile_leaves = 128;  // inputs per tile (bounded by the kernels' LDS use)
+  bool micro = true;              // first local stage uses micro tiles (64 x <= 3 leaves)
 };
 
 // 'leaf_slot[n]' gives, for every tree node n that is a leaf owned by my_rank,

@@ -35,17 +35,21 @@ typedef struct ihipStream_t* cedr_stream_t; /* == hipStream_t */
 
 /* One tile: a subtree one workgroup sweeps in LDS (see DESIGN.md "Tiles"). */
 typedef struct {
-  int32_t in0, nleaf, out, nint, kids_off, lvl_off, nlvl, pad;
+  int32_t in0, nleaf, out, nint, kids_off, lvl_off, nlvl, micro_off;
 } cedr_hip_tile;
 
 /* One stage: tiles that are swept by one kernel launch (max_nleaf <= 256).
  * Arrays are device memory. kids: 2 local node ids per internal node; lvlptr: per tile nlvl+1
- * offsets. */
+ * offsets. micro != NULL marks a MICRO stage: the nleaf (<= 64) inputs of a
+ * tile's LDS tree are subtrees of <= 3 consecutive cells, one per lane, handled
+ * in registers; micro[tile.micro_off + i] = first cell relative to in0 (low
+ * byte) | shape << 8, shape 0 = a, 1 = (a,b), 2 = ((a,b),c), 3 = (a,(b,c)). */
 typedef struct {
   int32_t ntiles, max_nodes, max_nint, max_nleaf;
   const cedr_hip_tile* tiles;
   const uint16_t* kids;
   const int32_t* lvlptr;
+  const uint16_t* micro;
 } cedr_hip_stage;
 
 /* QLT record layout. Bulk data are stored field-major:
@@ -225,12 +229,15 @@ void* cedr_qlt_nodesets(void* qlt); /* borrowed NodeSets handle for cedr_ns_* */
  * the one a QLT runs (valid while the QLT lives; do not free it).
  * summary[8] = {nlcl, nslots, #local stages, #top stages, root_slot, nb_max,
  *               #my boundary roots, stride}. */
+/* max_tile_leaves: 0 = defaults; > 0 sets the tile size; < 0 disables micro
+ * tiles (and -n, n > 1, sets the tile size n as well). */
 void* cedr_plan_create(void* tree, int ncells, int my_rank, int nranks, int max_tile_leaves);
 void cedr_plan_free(void* plan);
 void* cedr_qlt_plan(void* qlt);
 int cedr_plan_summary(void* plan, int64_t* summary8);
-/* sizes[4] = {ntiles, max_nodes, #internal nodes, #lvlptr entries} */
-int cedr_plan_stage_sizes(void* plan, int top, int idx, int* sizes4);
+/* sizes[5] = {ntiles, max_nodes, #internal nodes, #lvlptr entries, #micro entries} */
+int cedr_plan_stage_sizes(void* plan, int top, int idx, int* sizes5);
+int cedr_plan_stage_micro(void* plan, int top, int idx, uint16_t* micro);
 int cedr_plan_stage(void* plan, int top, int idx, int* tiles_x8, uint16_t* kids, int* lvlptr);
 /* my_root_slots[#my roots], my_top_slots[#my roots], gather_slots[nranks*nb_max] */
 int cedr_plan_exchange(void* plan, int* my_root_slots, int* my_top_slots, int* gather_slots);

@@ -32,21 +32,47 @@ def tile_local_nodes(stage, t):
     return in0, nleaf, out, nint, kids
 
 
+def tile_micro(stage, t):
+    """Micro tiles: list of (first cell relative to in0, shape) per LDS-tree input, or None."""
+    if not len(stage.get("micro", ())):
+        return None
+    nleaf, moff = int(stage["tiles"][t][1]), int(stage["tiles"][t][7])
+    d = stage["micro"][moff:moff + nleaf].astype(np.int64)
+    return [(int(x & 0xff), int(x >> 8)) for x in d]
+
+
+def _comb(ops, k0, k1, zero_init):
+    s = (0.0 + k0) + k1 if zero_init else k0 + k1
+    mn = np.where(k0 < k1, k0, k1)  # comparisons, as cedr_kokkos.hpp:136-139
+    mx = np.where(k0 > k1, k0, k1)
+    return np.where(ops == 0, s, np.where(ops == 1, mn, mx))
+
+
+def micro_cells(start, shape):
+    return [start + k for k in range(1 if shape == 0 else 2 if shape == 1 else 3)]
+
+
 def up_stage(stage, data, ops, zero_init=False):
     """data[field][slot]; mirrors tree_up_kernel."""
     for t in range(len(stage["tiles"])):
         in0, nleaf, out, nint, kids = tile_local_nodes(stage, t)
         v = np.zeros((data.shape[0], nleaf + nint))
-        v[:, :nleaf] = data[:, in0:in0 + nleaf]
+        mic = tile_micro(stage, t)
+        if mic is None:
+            v[:, :nleaf] = data[:, in0:in0 + nleaf]
+        else:
+            for i, (start, shape) in enumerate(mic):
+                c = [data[:, in0 + k] for k in micro_cells(start, shape)]
+                if shape == 0:
+                    v[:, i] = c[0]
+                elif shape == 1:
+                    v[:, i] = _comb(ops, c[0], c[1], zero_init)
+                elif shape == 2:
+                    v[:, i] = _comb(ops, _comb(ops, c[0], c[1], zero_init), c[2], zero_init)
+                else:
+                    v[:, i] = _comb(ops, c[0], _comb(ops, c[1], c[2], zero_init), zero_init)
         for j in range(nint):
-            k0, k1 = v[:, kids[j, 0]], v[:, kids[j, 1]]
-            if zero_init:
-                s = (0.0 + k0) + k1
-            else:
-                s = k0 + k1
-            mn = np.where(k0 < k1, k0, k1)  # comparisons, as cedr_kokkos.hpp:136-139
-            mx = np.where(k0 > k1, k0, k1)
-            v[:, nleaf + j] = np.where(ops == 0, s, np.where(ops == 1, mn, mx))
+            v[:, nleaf + j] = _comb(ops, v[:, kids[j, 0]], v[:, kids[j, 1]], zero_init)
         data[:, out] = v[:, nleaf + nint - 1 if nint else 0]
 
 
@@ -60,13 +86,34 @@ def root_compute(md, root, l2r, r2l):
             r2l[rb + 2, root] = l2r[lb + 2, root]
 
 
+def _solve(pt, rho_me, rec_me, X, rho0, rec0, rho1, rec1, qlo, qhi, prefer):
+    """One node problem on {lo, orig, hi} records, as the kernels call solve_node."""
+    t_only = bool(pt & CONSISTENT) and not (pt & SHAPEPRESERVE)
+    if t_only:
+        pd, k0d, k1d = [qlo, rec_me[1], qhi], [qlo, rec0[1], qhi], [qlo, rec1[1], qhi]
+    elif pt & NONNEGATIVE:
+        pd, k0d, k1d = [0, 0, 0], [rec0[1], 0, 0], [rec1[1], 0, 0]
+    else:
+        pd, k0d, k1d = rec_me[:3], rec0[:3], rec1[:3]
+    return o.solve_node_problem(pt, rho_me, pd, X, rho0, k0d, rho1, k1d, prefer)
+
+
 def down_stage(stage, md, l2r, r2l, prefer=False):
-    """Mirrors qlt_down_kernel."""
+    """Mirrors qlt_down_kernel / qlt_down_micro_kernel."""
     for t in range(len(stage["tiles"])):
         in0, nleaf, out, nint, kids = tile_local_nodes(stage, t)
+        mic = tile_micro(stage, t)
         nn = nleaf + nint
         rho = np.zeros(nn)
-        rho[:nleaf] = l2r[0, in0:in0 + nleaf]
+        if mic is None:
+            rho[:nleaf] = l2r[0, in0:in0 + nleaf]
+        else:
+            mrho = []  # per micro: (cell rhos, rho of inner pair t)
+            for i, (start, shape) in enumerate(mic):
+                c = [l2r[0, in0 + k] for k in micro_cells(start, shape)]
+                rt = (c[1] + c[2]) if shape == 3 else (c[0] + c[1]) if shape >= 1 else 0.0
+                rho[i] = c[0] if shape == 0 else rt if shape == 1 else (rt + c[2]) if shape == 2 else c[0] + rt
+                mrho.append((c, rt))
         for j in range(nint):
             rho[nleaf + j] = rho[kids[j, 0]] + rho[kids[j, 1]]
         root = nn - 1 if nint else 0
@@ -75,12 +122,28 @@ def down_stage(stage, md, l2r, r2l, prefer=False):
             lb, rb = md["trcr2bl2r"][ti], md["trcr2br2l"][ti]
             sp = bool(pt & SHAPEPRESERVE)
             t_only = bool(pt & CONSISTENT) and not sp
+            of = 1 if (sp or (pt & CONSISTENT)) else 0
+
+            def cell_rec(cell):
+                r = np.zeros(3)
+                if sp:
+                    r[:] = [l2r[lb + f, cell] for f in range(3)]
+                else:
+                    r[1] = l2r[lb + of, cell]
+                return r
+
             rec = np.zeros((nn, 4))
-            if sp:
-                for f in range(3):
-                    rec[:nleaf, f] = l2r[lb + f, in0:in0 + nleaf]
+            if mic is None:
+                for i in range(nleaf):
+                    rec[i, :3] = cell_rec(in0 + i)
             else:
-                rec[:nleaf, 1] = l2r[lb + (1 if pt & CONSISTENT else 0), in0:in0 + nleaf]
+                mrec = []  # per micro: (cell records, record of inner pair t)
+                for i, (start, shape) in enumerate(mic):
+                    c = [cell_rec(in0 + k) for k in micro_cells(start, shape)]
+                    tr = (c[1] + c[2]) if shape == 3 else (c[0] + c[1]) if shape >= 1 else np.zeros(3)
+                    rec[i, :3] = (c[0] if shape == 0 else tr if shape == 1 else (tr + c[2]) if shape == 2
+                                  else c[0] + tr)
+                    mrec.append((c, tr))
             for j in range(nint):
                 rec[nleaf + j, :3] = rec[kids[j, 0], :3] + rec[kids[j, 1], :3]
             rec[root, 3] = r2l[rb, out]
@@ -89,22 +152,34 @@ def down_stage(stage, md, l2r, r2l, prefer=False):
                 qlo, qhi = r2l[rb + 1, out], r2l[rb + 2, out]
             for j in range(nint - 1, -1, -1):
                 me, c0, c1 = nleaf + j, kids[j, 0], kids[j, 1]
+                rec[c0, 3], rec[c1, 3] = _solve(pt, rho[me], rec[me], rec[me, 3], rho[c0], rec[c0],
+                                                rho[c1], rec[c1], qlo, qhi, prefer)
+            if mic is None:
+                cells = [(in0 + i, rec[i, 3]) for i in range(nleaf)]
+            else:
+                cells = []
+                for i, (start, shape) in enumerate(mic):
+                    (c, tr), (cr, rt) = mrec[i], mrho[i]
+                    Xr = rec[i, 3]
+                    ids = [in0 + k for k in micro_cells(start, shape)]
+                    if shape == 0:
+                        X = [Xr]
+                    elif shape == 1:
+                        X = list(_solve(pt, rho[i], rec[i], Xr, cr[0], c[0], cr[1], c[1], qlo, qhi, prefer))
+                    elif shape == 2:
+                        Xt, Xc = _solve(pt, rho[i], rec[i], Xr, rt, tr, cr[2], c[2], qlo, qhi, prefer)
+                        Xa, Xb = _solve(pt, rt, tr, Xt, cr[0], c[0], cr[1], c[1], qlo, qhi, prefer)
+                        X = [Xa, Xb, Xc]
+                    else:
+                        Xa, Xt = _solve(pt, rho[i], rec[i], Xr, cr[0], c[0], rt, tr, qlo, qhi, prefer)
+                        Xb, Xc = _solve(pt, rt, tr, Xt, cr[1], c[1], cr[2], c[2], qlo, qhi, prefer)
+                        X = [Xa, Xb, Xc]
+                    cells += list(zip(ids, X))
+            for cell, x in cells:
+                r2l[rb, cell] = x
                 if t_only:
-                    pd = [qlo, rec[me, 1], qhi]
-                    k0d, k1d = [qlo, rec[c0, 1], qhi], [qlo, rec[c1, 1], qhi]
-                elif pt & NONNEGATIVE:
-                    pd = [0, 0, 0]
-                    k0d, k1d = [rec[c0, 1], 0, 0], [rec[c1, 1], 0, 0]
-                else:
-                    pd, k0d, k1d = rec[me, :3], rec[c0, :3], rec[c1, :3]
-                x = o.solve_node_problem(pt, rho[me], pd, rec[me, 3], rho[c0], k0d, rho[c1], k1d, prefer)
-                rec[c0, 3], rec[c1, 3] = x
-            r2l[rb, in0:in0 + nleaf] = rec[:nleaf, 3]
-            if t_only:
-                r2l[rb + 1, in0:in0 + nleaf] = qlo
-                r2l[rb + 2, in0:in0 + nleaf] = qhi
-                l2r[lb, in0:in0 + nleaf] = qlo
-                l2r[lb + 2, in0:in0 + nleaf] = qhi
+                    r2l[rb + 1, cell], r2l[rb + 2, cell] = qlo, qhi
+                    l2r[lb, cell], l2r[lb + 2, cell] = qlo, qhi
 
 
 class RankState:

@@ -52,12 +52,14 @@ def run_plan(ca, nc, P, tree_args, types, v, prefer=False):
     return out
 
 
+@pytest.mark.parametrize("micro", ["0", "1"])
 @pytest.mark.parametrize("nc,P,pseudorandom,imbalanced", [
     (1, 1, False, False), (2, 1, False, False), (37, 1, False, True), (200, 1, False, False),
-    (2, 2, False, False), (24, 2, False, False), (60, 3, False, True), (64, 8, False, False),
-    (56, 8, True, False), (40, 4, True, True)])
-def test_plan_execution_matches_oracle(ca, oracle, nc, P, pseudorandom, imbalanced, monkeypatch):
+    (700, 1, False, False), (2, 2, False, False), (24, 2, False, False), (60, 3, False, True),
+    (64, 8, False, False), (56, 8, True, False), (40, 4, True, True)])
+def test_plan_execution_matches_oracle(ca, oracle, nc, P, pseudorandom, imbalanced, micro, monkeypatch):
     monkeypatch.setenv("CEDR_HIP_TILE_LEAVES", "8")  # several stages even on small trees
+    monkeypatch.setenv("CEDR_HIP_MICRO", micro)
     trs = R.tracers_vector()[:12]  # all six problem types, two perturbations
     types = [t.problem_type for t in trs]
     v = R.make_values(trs, nc, seed=nc + P)
@@ -70,7 +72,7 @@ def test_plan_execution_matches_oracle(ca, oracle, nc, P, pseudorandom, imbalanc
 def test_plan_invariants(ca, tile):
     nc = 1000
     tree = ca.Tree.make_1d(nc, 1, False, True)
-    pl = tree.plan(nc, 0, 1, tile)
+    pl = tree.plan(nc, 0, 1, -tile)  # micro tiles off: every tile input is one slot
     assert pl["nlcl"] == nc
     seen = np.zeros(pl["nslots"], np.int32)
     covered = np.zeros(pl["nslots"], np.int32)
@@ -90,6 +92,30 @@ def test_plan_invariants(ca, tile):
     assert (seen[nc:] == 1).all() and (seen[:nc] == 0).all()
     assert (covered[:pl["root_slot"]] == 1).all() and covered[pl["root_slot"]] == 0
     assert pl["stride"] % 16 == 0 and pl["stride"] >= pl["nslots"]
+
+
+@pytest.mark.parametrize("imbalanced", [False, True])
+def test_micro_plan_invariants(ca, imbalanced):
+    """First stage with micro tiles: <= 64 micro-subtrees of <= 3 consecutive cells per
+    tile, every cell in exactly one of them."""
+    nc = 5000
+    pl = ca.Tree.make_1d(nc, 1, False, imbalanced).plan(nc, 0, 1, 0)
+    st = pl["local"][0]
+    assert len(st["micro"]) > 0
+    covered = np.zeros(nc, np.int32)
+    for t in st["tiles"]:
+        in0, nleaf, out, nint, koff, loff, nlvl, moff = [int(x) for x in t]
+        assert 1 <= nleaf <= 64 and nint == nleaf - 1
+        prev_end = 0
+        for d in st["micro"][moff:moff + nleaf]:
+            start, shape = int(d & 0xff), int(d >> 8)
+            size = 1 if shape == 0 else 2 if shape == 1 else 3
+            assert start == prev_end and 0 <= shape <= 3
+            covered[in0 + start:in0 + start + size] += 1
+            prev_end = start + size
+    assert (covered == 1).all()
+    for later in pl["local"][1:]:
+        assert len(later["micro"]) == 0
 
 
 def test_multirank_plan_shapes(ca):

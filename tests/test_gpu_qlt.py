@@ -57,17 +57,24 @@ def test_qlt_config_A(gpu, oracle):
     assert (got >= v.Qm_min).all() and (got <= v.Qm_max).all()
 
 
-@pytest.mark.parametrize("tile", [2, 3, 16, 128])
-def test_qlt_tile_size_invariance(gpu, oracle, tile, monkeypatch):
-    """Results cannot depend on how the tree is cut into tiles."""
+@pytest.mark.parametrize("micro", ["0", "1"])
+@pytest.mark.parametrize("tile", [2, 3, 16, 128, 256])
+def test_qlt_tile_size_invariance(gpu, oracle, tile, micro, monkeypatch):
+    """Results cannot depend on how the tree is cut into tiles (micro tiles or not)."""
     ca = gpu
     monkeypatch.setenv("CEDR_HIP_TILE_LEAVES", str(tile))
+    monkeypatch.setenv("CEDR_HIP_MICRO", micro)
     trs = R.tracers_vector()
     v = R.make_values(trs, 333, seed=5)
     want = common.run_oracle_qlt(oracle, (False, True), 333, 1, _types(trs), v)
     q = common.make_hip_qlt(ca, ca.Tree.make_1d(333, 1, False, True), 333, _types(trs))
     got = common.run_hip_qlt(ca, q, v)
     assert np.array_equal(got, want)
+    # a balanced tree too (micro shapes (a,b) and (a,(b,c)) dominate there)
+    v2 = R.make_values(trs, 1500, seed=6)
+    want2 = common.run_oracle_qlt(oracle, (False, False), 1500, 1, _types(trs), v2)
+    q2 = common.make_hip_qlt(ca, ca.Tree.make_1d(1500), 1500, _types(trs))
+    assert np.array_equal(common.run_hip_qlt(ca, q2, v2), want2)
 
 
 def test_qlt_interleaved_types_and_errors(gpu, oracle):
