@@ -19,7 +19,8 @@ __all__ = ["CedrError", "ProblemType", "Parallel", "Tree", "QLT", "CAAS", "BfbTr
            "DeviceArray", "lib", "LIB_PATH", "build", "device_count"]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcedr_hip.so")
+# CEDR_HIP_LIB selects another build of the same library (kernel tuning experiments).
+LIB_PATH = os.environ.get("CEDR_HIP_LIB") or os.path.join(_HERE, "libcedr_hip.so")
 
 
 class CedrError(RuntimeError):
