@@ -38,6 +38,11 @@ def parse():
     ap.add_argument("--cpu-cells", type=int, default=375000,
                     help="cells of the bounded CPU-baseline sample (same tracer count)")
     ap.add_argument("--check", action="store_true", help="verify properties of the results")
+    ap.add_argument("--comm", choices=["rccl", "gloo"], default="rccl",
+                    help="data-path transport for N > 1: the library's RCCL communicator (default) or, "
+                         "for rehearsals on one GPU, host-staged torch.distributed/gloo callbacks")
+    ap.add_argument("--same-gpu", action="store_true",
+                    help="rehearsal: every rank uses GPU 0 (needs --comm gloo)")
     return ap.parse_args()
 
 
@@ -116,6 +121,8 @@ def main():
         raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, a.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback)")
+    if a.same_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     torch.zeros(1, device=device)  # initialise the HIP context before the library is used
@@ -123,9 +130,21 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo", rank=rank, world_size=world)
-        uid = [ca.Parallel.rccl_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        par = ca.Parallel.rccl(uid[0], rank, world)
+        if a.comm == "rccl":
+            uid = [ca.Parallel.rccl_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            par = ca.Parallel.rccl(uid[0], rank, world)
+        else:
+            def ag_host(x):
+                bufs = [torch.zeros(len(x), dtype=torch.float64) for _ in range(world)]
+                dist.all_gather(bufs, torch.from_numpy(x))
+                return torch.cat(bufs).numpy()
+
+            def ar_host(x):
+                t = torch.from_numpy(x.copy())
+                dist.all_reduce(t)
+                return t.numpy()
+            par = ca.Parallel.host_staged(rank, world, ag_host, ar_host)
     else:
         par = ca.Parallel.self_()
 
@@ -266,7 +285,8 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "QLT::run + CAAS::run, %d cells x %d cst tracers, balanced 1-D tree, "
                                    "contiguous %d-way sharding" % (ncells, nt, world),
-                       "ncells": ncells, "ntracers": nt, "cells_per_gpu": n},
+                       "ncells": ncells, "ntracers": nt, "cells_per_gpu": n,
+                       "transport": a.comm if world > 1 else "none"},
             "qlt": {"ms_per_run": 1e3 * t_qlt, "updates_per_s": ncells * nt / t_qlt},
             "caas": {"ms_per_run": 1e3 * t_caas, "updates_per_s": ncells * nt / t_caas},
             "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu,

@@ -269,6 +269,28 @@ class Parallel:
         ar = ALLREDUCE_FN(lambda user, s, r, n, st: int(allreduce_sum(s, r, n, st) or 0))
         return Parallel(lib().cedr_parallel_create_callbacks(rank, size, ag, ar, None), keep=(ag, ar))
 
+    @staticmethod
+    def host_staged(rank, size, allgather_host, allreduce_host):
+        """Rehearsal transport: the two collectives run on HOST numpy arrays supplied by the
+        caller (e.g. torch.distributed/gloo); device buffers are staged through hipMemcpy.
+        allgather_host(send[count]) -> recv[size*count]; allreduce_host(send[count]) -> recv[count]."""
+        L = lib()
+
+        def ag(s, r, n, st):
+            a = np.empty(n)
+            _chk(L.cedr_memcpy_d2h(a.ctypes.data, s, a.nbytes), "d2h")
+            out = np.ascontiguousarray(allgather_host(a), np.float64)
+            _chk(L.cedr_memcpy_h2d(r, out.ctypes.data, out.nbytes), "h2d")
+            return 0
+
+        def ar(s, r, n, st):
+            a = np.empty(n)
+            _chk(L.cedr_memcpy_d2h(a.ctypes.data, s, a.nbytes), "d2h")
+            out = np.ascontiguousarray(allreduce_host(a), np.float64)
+            _chk(L.cedr_memcpy_h2d(r, out.ctypes.data, out.nbytes), "h2d")
+            return 0
+        return Parallel.callbacks(rank, size, ag, ar)
+
     def rank(self):
         return lib().cedr_parallel_rank(self.h)
 
