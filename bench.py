@@ -38,6 +38,8 @@ def parse():
     ap.add_argument("--cpu-cells", type=int, default=375000,
                     help="cells of the bounded CPU-baseline sample (same tracer count)")
     ap.add_argument("--check", action="store_true", help="verify properties of the results")
+    ap.add_argument("--serial", action="store_true",
+                    help="run QLT and CAAS back to back on one stream instead of on two concurrent streams")
     ap.add_argument("--comm", choices=["rccl", "gloo"], default="rccl",
                     help="data-path transport for N > 1: the library's RCCL communicator (default) or, "
                          "for rehearsals on one GPU, host-staged torch.distributed/gloo callbacks")
@@ -169,6 +171,13 @@ def main():
     caas.set_Qm(Qm, Qm_min, Qm_max, Qm_prev)
     caas.set_Qm_source(Qm)  # every run() reads the pristine Qm: identical work each step
     torch.cuda.synchronize()
+    # QLT and CAAS are independent CDRs: each gets its own HIP stream so that the
+    # latency-bound upper stages / collectives of one overlap the streaming kernels of the other.
+    streams = None
+    if not a.serial:
+        streams = (torch.cuda.Stream(device=device), torch.cuda.Stream(device=device))
+        qlt.set_stream(streams[0].cuda_stream)
+        caas.set_stream(streams[1].cuda_stream)
 
     def barrier():
         if world > 1:
@@ -214,7 +223,12 @@ def main():
     t_caas = timed(caas.run)
 
     # Roofline leg: HIP events around every kernel launch, on the launch stream,
-    # over `steps` more steps of the same loop.
+    # over `steps` more steps of the same loop, with the two CDRs on ONE stream so
+    # that a kernel's duration is not stretched by a concurrent one.
+    if streams:
+        torch.cuda.synchronize()
+        qlt.set_stream(None)
+        caas.set_stream(None)
     ca.profile_start()
     for _ in range(a.steps):
         step()
@@ -283,8 +297,9 @@ def main():
             "value": value, "unit": "cell-tracer-updates/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "QLT::run + CAAS::run, %d cells x %d cst tracers, balanced 1-D tree, "
-                                   "contiguous %d-way sharding" % (ncells, nt, world),
+            "config": {"workload": "QLT::run + CAAS::run%s, %d cells x %d cst tracers, balanced 1-D tree, "
+                                   "contiguous %d-way sharding" % (" on two concurrent streams" if streams else "",
+                                                                   ncells, nt, world),
                        "ncells": ncells, "ntracers": nt, "cells_per_gpu": n,
                        "transport": a.comm if world > 1 else "none"},
             "qlt": {"ms_per_run": 1e3 * t_qlt, "updates_per_s": ncells * nt / t_qlt},

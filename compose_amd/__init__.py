@@ -111,7 +111,7 @@ _SIGS = {
     "cedr_plan_summary": (C.c_int, [_vp, C.POINTER(C.c_int64)]),
     "cedr_plan_stage_sizes": (C.c_int, [_vp, C.c_int, C.c_int, _ip]),
     "cedr_plan_stage": (C.c_int, [_vp, C.c_int, C.c_int, _ip, C.POINTER(C.c_uint16), _ip]),
-    "cedr_plan_stage_micro": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(C.c_uint16)]),
+    "cedr_plan_stage_micro": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(C.c_uint16), C.POINTER(C.c_uint16)]),
     "cedr_plan_exchange": (C.c_int, [_vp, _ip, _ip, _ip]),
     "cedr_caas_create": (_vp, [_vp, C.c_int, USER_ALLREDUCE_FN, C.c_int, _vp]),
     "cedr_caas_free": (None, [_vp]),
@@ -381,17 +381,19 @@ def dump_plan(h, nranks=1):
                local=[], top=[])
     for top, key, cnt in ((0, "local", s[2]), (1, "top", s[3])):
         for i in range(cnt):
-            sz = (C.c_int * 5)()
+            sz = (C.c_int * 6)()
             _chk(L.cedr_plan_stage_sizes(h, top, i, sz))
-            tiles = np.zeros((sz[0], 8), np.int32)
+            tiles = np.zeros((sz[0], 10), np.int32)
             kids = np.zeros((sz[2], 2), np.uint16)
             lvlptr = np.zeros(sz[3], np.int32)
             _chk(L.cedr_plan_stage(h, top, i, tiles.ctypes.data_as(_ip),
                                    kids.ctypes.data_as(C.POINTER(C.c_uint16)), lvlptr.ctypes.data_as(_ip)))
-            micro = np.zeros(sz[4], np.uint16)
-            if sz[4]:
-                _chk(L.cedr_plan_stage_micro(h, top, i, micro.ctypes.data_as(C.POINTER(C.c_uint16))))
-            out[key].append(dict(tiles=tiles, kids=kids, lvlptr=lvlptr, max_nodes=sz[1], micro=micro))
+            micro = np.zeros(max(sz[4], 1), np.uint16)
+            outs = np.zeros(max(sz[5], 1), np.uint16)
+            _chk(L.cedr_plan_stage_micro(h, top, i, micro.ctypes.data_as(C.POINTER(C.c_uint16)),
+                                         outs.ctypes.data_as(C.POINTER(C.c_uint16))))
+            out[key].append(dict(tiles=tiles, kids=kids, lvlptr=lvlptr, max_nodes=sz[1],
+                                 micro=micro[:sz[4]], outs=outs[:sz[5]]))
     out["my_root_slots"], out["my_top_slots"], out["gather_slots"] = plan_exchange(h, nranks)
     return out
 

@@ -3,6 +3,7 @@
 // message retrievable with cedr_last_error().
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <exception>
 #include <map>
@@ -235,6 +236,7 @@ void* cedr_plan_create (void* tree, int ncells, int my_rank, int nranks, int max
   plan::Options o;
   if (max_tile_leaves > 0) o.max_tile_leaves = max_tile_leaves;
   if (max_tile_leaves < 0) { o.micro = false; if (max_tile_leaves < -1) o.max_tile_leaves = -max_tile_leaves; }
+  if (const char* e = std::getenv("CEDR_HIP_MICRO_CUT")) o.micro_cut = std::atoi(e);
   PlanBox* b = new PlanBox();
   b->owned = plan::build(t, my_rank, nranks, leaf_slot, o);
   b->p = &b->owned;
@@ -269,12 +271,14 @@ int cedr_plan_stage_sizes (void* h, int top, int idx, int* sz) {
   sz[0] = static_cast<int>(st->tiles.size()); sz[1] = st->max_nodes;
   sz[2] = static_cast<int>(st->kids.size()/2); sz[3] = static_cast<int>(st->lvlptr.size());
   sz[4] = static_cast<int>(st->micro.size());
+  sz[5] = static_cast<int>(st->outs.size());
   return 0;
 }
-int cedr_plan_stage_micro (void* h, int top, int idx, uint16_t* micro) {
+int cedr_plan_stage_micro (void* h, int top, int idx, uint16_t* micro, uint16_t* outs) {
   const plan::Stage* st = get_stage(h, top, idx);
   if ( ! st) { g_err = "no such stage"; return -1; }
   std::copy(st->micro.begin(), st->micro.end(), micro);
+  std::copy(st->outs.begin(), st->outs.end(), outs);
   return 0;
 }
 int cedr_plan_stage (void* h, int top, int idx, int* tiles, uint16_t* kids, int* lvlptr) {

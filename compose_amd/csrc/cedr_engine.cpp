@@ -15,7 +15,8 @@ void DeviceStage::upload (const plan::Stage& st) {
   std::vector<cedr_hip_tile> tl(st.tiles.size());
   for (size_t i = 0; i < tl.size(); ++i) {
     const plan::Tile& s = st.tiles[i];
-    tl[i] = cedr_hip_tile{s.in0, s.nleaf, s.out, s.nint, s.kids_off, s.lvl_off, s.nlvl, s.micro_off};
+    tl[i] = cedr_hip_tile{s.in0, s.nleaf, s.out, s.nint, s.kids_off, s.lvl_off, s.nlvl, s.micro_off,
+                          s.nout, s.outs_off};
   }
   tiles.upload(tl);
   kids.upload(st.kids);
@@ -29,6 +30,8 @@ void DeviceStage::upload (const plan::Stage& st) {
   h.lvlptr = lvlptr.data();
   micro.upload(st.micro);
   h.micro = st.micro.empty() ? nullptr : micro.data();
+  outs.upload(st.outs);
+  h.outs = outs.data();
 }
 
 TreeEngine::TreeEngine (const mpi::Parallel::Ptr& p, const tree::FlatTree& t,

@@ -16,7 +16,7 @@ namespace engine {
 
 struct DeviceStage {
   dev::Buffer<cedr_hip_tile> tiles;
-  dev::Buffer<uint16_t> kids, micro;
+  dev::Buffer<uint16_t> kids, micro, outs;
   dev::Buffer<int32_t> lvlptr;
   cedr_hip_stage h;
   void upload(const plan::Stage& st);

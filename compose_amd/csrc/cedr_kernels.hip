@@ -76,7 +76,6 @@ void tree_up_kernel (const cedr_hip_stage st, const int nfields, const uint8_t* 
   double cur[NR][NI];
   if (static_cast<int>(blockIdx.y) < nchunks) load(blockIdx.y, cur);
   stage_tile_meta(st, tile, kidsL, lvlL);
-  const int root = tile.nint ? nleaf + tile.nint - 1 : 0;
   const int ff = threadIdx.x & (FT - 1);  // this thread's field within a chunk
   double* const vf = v + ff*pitch;
 
@@ -111,8 +110,9 @@ void tree_up_kernel (const cedr_hip_stage st, const int nfields, const uint8_t* 
       }
       __syncthreads();
     }
-    if (threadIdx.x < FT && f < nfields)
-      data[static_cast<size_t>(f)*stride + tile.out] = vf[root];
+    if (f < nfields)
+      for (int k = threadIdx.x >> Log2<FT>::value; k < tile.nout; k += kBlock/FT)
+        data[static_cast<size_t>(f)*stride + tile.out + k] = vf[st.outs[tile.outs_off + k]];
     __syncthreads();  // the next chunk overwrites v
 #pragma unroll
     for (int r = 0; r < NR; ++r)
@@ -192,7 +192,6 @@ void qlt_down_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st,
     rw[i] = w;
     rq[i] = 1.0/w;
   }
-  const int root = tile.nint ? nleaf + tile.nint - 1 : 0;
   const int tt = threadIdx.x & (TT - 1);  // this thread's tracer within a chunk
   double* const R = recs + tt*pitch;
 
@@ -208,9 +207,8 @@ void qlt_down_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st,
     const bool t_only = (pt & CONSISTENT) && ! sp;
     // The tile root's assigned mass, and for a t-only tracer the global q
     // bounds, which travel root->leaves unchanged (cedr_qlt.cpp:549-560).
-    double Xroot = 0, qlo = 0, qhi = 0;
+    double qlo = 0, qhi = 0;
     if (live) {
-      Xroot = r2l[static_cast<size_t>(rb)*S + tile.out];
       if (t_only) {
         qlo = r2l[static_cast<size_t>(rb + 1)*S + tile.out];
         qhi = r2l[static_cast<size_t>(rb + 2)*S + tile.out];
@@ -243,7 +241,9 @@ void qlt_down_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st,
       __syncthreads();
     }
     // Phase B: node problems, level by level from the tile root.
-    if (threadIdx.x < TT) R[4*root + 3] = Xroot;
+    if (live)
+      for (int k = threadIdx.x >> Log2<TT>::value; k < tile.nout; k += kBlock/TT)
+        R[4*st.outs[tile.outs_off + k] + 3] = r2l[static_cast<size_t>(rb)*S + tile.out + k];
     __syncthreads();
     for (int lv = tile.nlvl - 1; lv >= 0; --lv) {
       const int a = lvlL[lv];
@@ -361,7 +361,6 @@ void tree_up_micro_kernel (const cedr_hip_stage st, const int nfields,
   double cur[NR][3];
   if (static_cast<int>(blockIdx.y) < nchunks) load(blockIdx.y, cur);
   stage_tile_meta(st, tile, kidsL, lvlL);
-  const int root = tile.nint ? nleaf + tile.nint - 1 : 0;
   const int ff = threadIdx.x & (FT - 1);
   double* const vf = v + ff*pitch;
 
@@ -389,8 +388,9 @@ void tree_up_micro_kernel (const cedr_hip_stage st, const int nfields,
       }
       __syncthreads();
     }
-    if (threadIdx.x < FT && f < nfields)
-      data[static_cast<size_t>(f)*stride + tile.out] = vf[root];
+    if (f < nfields)
+      for (int k = threadIdx.x >> Log2<FT>::value; k < tile.nout; k += kBlock/FT)
+        data[static_cast<size_t>(f)*stride + tile.out + k] = vf[st.outs[tile.outs_off + k]];
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < NR; ++r)
@@ -490,7 +490,6 @@ void qlt_down_micro_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st
     rw[i] = w;
     rq[i] = 1.0/w;
   }
-  const int root = tile.nint ? nleaf + tile.nint - 1 : 0;
   const int tt = threadIdx.x & (TT - 1);  // tracer of this thread in the LDS phases
   double* const R = recs + tt*pitch;      // its record row
   double* const Rw = recs + wave*pitch;   // record row of this wave's tracer
@@ -528,9 +527,8 @@ void qlt_down_micro_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st
     const int rb = live ? L.bidx_r2l[bi] : 0;
     const bool sp = (pt & SHAPEPRESERVE) != 0;
     const bool t_only = (pt & CONSISTENT) && ! sp;
-    double Xroot = 0, qlo = 0, qhi = 0;
+    double qlo = 0, qhi = 0;
     if (live) {
-      Xroot = r2l[static_cast<size_t>(rb)*S + tile.out];
       if (t_only) {
         qlo = r2l[static_cast<size_t>(rb + 1)*S + tile.out];
         qhi = r2l[static_cast<size_t>(rb + 2)*S + tile.out];
@@ -551,7 +549,9 @@ void qlt_down_micro_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st
       }
       __syncthreads();
     }
-    if (threadIdx.x < TT) R[4*root + 3] = Xroot;
+    if (live)
+      for (int k = threadIdx.x >> Log2<TT>::value; k < tile.nout; k += kBlock/TT)
+        R[4*st.outs[tile.outs_off + k] + 3] = r2l[static_cast<size_t>(rb)*S + tile.out + k];
     __syncthreads();
     for (int lv = tile.nlvl - 1; lv >= 0; --lv) {
       const int a = lvlL[lv];

@@ -17,6 +17,8 @@ struct Builder {
   std::vector<int32_t> lid;    // scratch: local id inside the tile being built
   std::vector<int32_t> llvl;   // scratch: local level inside the tile being built
   std::vector<int32_t> nleaves; // # real leaves below a node (filled by the caller)
+  std::vector<int32_t> first_in; // scratch: local id of a node's first input
+  std::vector<char> has_parent;  // scratch: node has a kept parent in the tile
   bool micro_mode = false;     // inputs are micro-subtrees (<= 3 leaves) instead of slots
   int32_t next_slot;
 
@@ -26,7 +28,7 @@ struct Builder {
 
   Builder (const tree::FlatTree& t_, const Options& o)
     : t(t_), opt(o), slot(t_.size(), -1), cnt(t_.size(), 0), lid(t_.size(), -1),
-      llvl(t_.size(), 0), next_slot(0) {}
+      llvl(t_.size(), 0), first_in(t_.size(), 0), has_parent(t_.size(), 0), next_slot(0) {}
 
   // cnt[n] for every node reachable from r without passing through an input.
   void count_inputs (const int32_t r) {
@@ -54,8 +56,8 @@ struct Builder {
     int32_t nreal = 0;  // real leaves seen so far (micro mode)
     tile.kids_off = static_cast<int32_t>(st.kids.size()/2);
     tile.lvl_off = static_cast<int32_t>(st.lvlptr.size());
-    tile.out = next_slot++;
     std::vector<int32_t> internals;  // post-order
+    std::vector<int32_t> inputs;     // DFS order
     int32_t nleaf = 0, in0 = -1;
     {
       std::vector<std::pair<int32_t,int32_t> > stack;
@@ -93,6 +95,7 @@ struct Builder {
           }
           lid[n] = nleaf++;
           llvl[n] = 0;
+          inputs.push_back(n);
           stack.pop_back();
           continue;
         }
@@ -105,6 +108,14 @@ struct Builder {
           stack.pop_back();
         }
       }
+    }
+    // Cut tiles keep only the internal nodes of local level <= cut.
+    const int32_t cut = (micro_mode && opt.micro_cut > 0) ? opt.micro_cut : 0;
+    std::vector<int32_t> dropped;
+    if (cut > 0) {
+      std::vector<int32_t> keep;
+      for (const int32_t n : internals) (llvl[n] <= cut ? keep : dropped).push_back(n);
+      internals.swap(keep);
     }
     tile.in0 = in0;
     tile.nleaf = nleaf;
@@ -128,11 +139,35 @@ struct Builder {
       st.kids.push_back(static_cast<uint16_t>(lid[t.kid1[n]]));
     }
     if ( ! internals.empty()) { st.lvlptr.push_back(tile.nint); ++tile.nlvl; }
+    // Outputs: kept nodes (inputs or internal) without a kept parent, in DFS
+    // order. lid is increasing along the DFS for inputs; an internal node sits
+    // where its first input sits.
+    std::vector<int32_t> outs;
+    if (dropped.empty()) {
+      outs.push_back(r);
+    } else {
+      for (const int32_t n : inputs) has_parent[n] = 0;
+      for (const int32_t n : internals) has_parent[n] = 0;
+      for (const int32_t n : internals) has_parent[t.kid0[n]] = has_parent[t.kid1[n]] = 1;
+      for (const int32_t n : inputs) { first_in[n] = lid[n]; if ( ! has_parent[n]) outs.push_back(n); }
+      for (const int32_t n : internals) {  // level order: kids are done before parents
+        first_in[n] = first_in[t.kid0[n]];
+        if ( ! has_parent[n]) outs.push_back(n);
+      }
+      std::sort(outs.begin(), outs.end(),
+                [&] (int32_t a, int32_t b) { return first_in[a] < first_in[b]; });
+    }
+    tile.out = next_slot;
+    tile.nout = static_cast<int32_t>(outs.size());
+    tile.outs_off = static_cast<int32_t>(st.outs.size());
+    for (const int32_t n : outs) {
+      st.outs.push_back(static_cast<uint16_t>(lid[n]));
+      pending.push_back(std::make_pair(n, next_slot++));
+    }
     st.max_nodes = std::max(st.max_nodes, tile.nleaf + tile.nint);
     st.max_nint = std::max(st.max_nint, tile.nint);
     st.max_nleaf = std::max(st.max_nleaf, tile.nleaf);
     st.tiles.push_back(tile);
-    pending.push_back(std::make_pair(r, tile.out));
   }
 
   std::vector<std::pair<int32_t,int32_t> > pending;  // (tile root, out slot) of the stage

@@ -37,12 +37,14 @@ namespace plan {
 struct Tile {
   int32_t in0;       // first input slot
   int32_t nleaf;     // number of inputs of the LDS tree (slots, or micro-subtrees)
-  int32_t out;       // slot the tile root's record is written to / read from
+  int32_t out;       // first output slot: output k of the tile lives in slot out + k
   int32_t nint;      // number of internal nodes
   int32_t kids_off;  // offset of this tile's first internal node in Stage::kids (pairs)
   int32_t lvl_off;   // offset into Stage::lvlptr
   int32_t nlvl;      // number of local levels of internal nodes
   int32_t micro_off; // micro tiles: offset into Stage::micro; else 0
+  int32_t nout;      // number of outputs (1 = the tile root, unless the tile is cut)
+  int32_t outs_off;  // offset into Stage::outs of the outputs' local node ids
 };
 
 struct Stage {
@@ -56,6 +58,13 @@ struct Stage {
   // to the tile's in0 (low byte) and shape (high byte): 0 = one leaf a,
   // 1 = (a,b), 2 = ((a,b),c), 3 = (a,(b,c)).
   std::vector<uint16_t> micro;
+  // Local node ids of every tile's outputs, in DFS order. A tile normally has
+  // one output, its root. A CUT tile keeps only the lowest 'cut' local levels
+  // of its tree in this stage; the subtrees' roots at that height are its
+  // outputs and the nodes above them are left to the next stage, which sees
+  // the outputs as consecutive input slots. Cutting shortens the chain of
+  // dependent tree levels a workgroup has to walk per tile.
+  std::vector<uint16_t> outs;
 };
 
 struct Plan {
@@ -79,6 +88,7 @@ struct Plan {
 struct Options {
   int32_t max_tile_leaves = 128;  // inputs per tile (bounded by the kernels' LDS use)
   bool micro = true;              // first local stage uses micro tiles (64 x <= 3 leaves)
+  int32_t micro_cut = 3;          // local levels kept per micro tile (0 = keep all)
 };
 
 // 'leaf_slot[n]' gives, for every tree node n that is a leaf owned by my_rank,

@@ -33,9 +33,11 @@ typedef struct ihipStream_t* cedr_stream_t; /* == hipStream_t */
 
 /* ------------------------------------------------------------------ layer K */
 
-/* One tile: a subtree one workgroup sweeps in LDS (see DESIGN.md "Tiles"). */
+/* One tile: a subtree one workgroup sweeps in LDS (see DESIGN.md "Tiles").
+ * Output k (k < nout) is local node outs[outs_off + k] and lives in slot out + k;
+ * normally nout = 1 (the tile root). */
 typedef struct {
-  int32_t in0, nleaf, out, nint, kids_off, lvl_off, nlvl, micro_off;
+  int32_t in0, nleaf, out, nint, kids_off, lvl_off, nlvl, micro_off, nout, outs_off;
 } cedr_hip_tile;
 
 /* One stage: tiles that are swept by one kernel launch (max_nleaf <= 256).
@@ -50,6 +52,7 @@ typedef struct {
   const uint16_t* kids;
   const int32_t* lvlptr;
   const uint16_t* micro;
+  const uint16_t* outs;
 } cedr_hip_stage;
 
 /* QLT record layout. Bulk data are stored field-major:
@@ -235,10 +238,11 @@ void* cedr_plan_create(void* tree, int ncells, int my_rank, int nranks, int max_
 void cedr_plan_free(void* plan);
 void* cedr_qlt_plan(void* qlt);
 int cedr_plan_summary(void* plan, int64_t* summary8);
-/* sizes[5] = {ntiles, max_nodes, #internal nodes, #lvlptr entries, #micro entries} */
-int cedr_plan_stage_sizes(void* plan, int top, int idx, int* sizes5);
-int cedr_plan_stage_micro(void* plan, int top, int idx, uint16_t* micro);
-int cedr_plan_stage(void* plan, int top, int idx, int* tiles_x8, uint16_t* kids, int* lvlptr);
+/* sizes[6] = {ntiles, max_nodes, #internal nodes, #lvlptr entries, #micro entries,
+ *             #outs entries}; tiles are 10 ints each (cedr_hip_tile) */
+int cedr_plan_stage_sizes(void* plan, int top, int idx, int* sizes6);
+int cedr_plan_stage_micro(void* plan, int top, int idx, uint16_t* micro, uint16_t* outs);
+int cedr_plan_stage(void* plan, int top, int idx, int* tiles_x10, uint16_t* kids, int* lvlptr);
 /* my_root_slots[#my roots], my_top_slots[#my roots], gather_slots[nranks*nb_max] */
 int cedr_plan_exchange(void* plan, int* my_root_slots, int* my_top_slots, int* gather_slots);
 

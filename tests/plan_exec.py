@@ -32,6 +32,12 @@ def tile_local_nodes(stage, t):
     return in0, nleaf, out, nint, kids
 
 
+def tile_outs(stage, t):
+    """Local node ids of the tile's outputs; output k lives in slot out + k."""
+    nout, ooff = int(stage["tiles"][t][8]), int(stage["tiles"][t][9])
+    return [int(x) for x in stage["outs"][ooff:ooff + nout]]
+
+
 def tile_micro(stage, t):
     """Micro tiles: list of (first cell relative to in0, shape) per LDS-tree input, or None."""
     if not len(stage.get("micro", ())):
@@ -73,7 +79,8 @@ def up_stage(stage, data, ops, zero_init=False):
                     v[:, i] = _comb(ops, c[0], _comb(ops, c[1], c[2], zero_init), zero_init)
         for j in range(nint):
             v[:, nleaf + j] = _comb(ops, v[:, kids[j, 0]], v[:, kids[j, 1]], zero_init)
-        data[:, out] = v[:, nleaf + nint - 1 if nint else 0]
+        for k, lid in enumerate(tile_outs(stage, t)):
+            data[:, out + k] = v[:, lid]
 
 
 def root_compute(md, root, l2r, r2l):
@@ -116,7 +123,7 @@ def down_stage(stage, md, l2r, r2l, prefer=False):
                 mrho.append((c, rt))
         for j in range(nint):
             rho[nleaf + j] = rho[kids[j, 0]] + rho[kids[j, 1]]
-        root = nn - 1 if nint else 0
+        outs = tile_outs(stage, t)
         for ti, pt in enumerate(md["trcr2prob"]):
             pt = int(pt)
             lb, rb = md["trcr2bl2r"][ti], md["trcr2br2l"][ti]
@@ -146,7 +153,8 @@ def down_stage(stage, md, l2r, r2l, prefer=False):
                     mrec.append((c, tr))
             for j in range(nint):
                 rec[nleaf + j, :3] = rec[kids[j, 0], :3] + rec[kids[j, 1], :3]
-            rec[root, 3] = r2l[rb, out]
+            for k, lid in enumerate(outs):
+                rec[lid, 3] = r2l[rb, out + k]
             qlo = qhi = 0.0
             if t_only:
                 qlo, qhi = r2l[rb + 1, out], r2l[rb + 2, out]

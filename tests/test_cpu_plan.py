@@ -52,14 +52,16 @@ def run_plan(ca, nc, P, tree_args, types, v, prefer=False):
     return out
 
 
-@pytest.mark.parametrize("micro", ["0", "1"])
+@pytest.mark.parametrize("micro", ["0", "1", "cut0", "cut1"])
 @pytest.mark.parametrize("nc,P,pseudorandom,imbalanced", [
     (1, 1, False, False), (2, 1, False, False), (37, 1, False, True), (200, 1, False, False),
     (700, 1, False, False), (2, 2, False, False), (24, 2, False, False), (60, 3, False, True),
     (64, 8, False, False), (56, 8, True, False), (40, 4, True, True)])
 def test_plan_execution_matches_oracle(ca, oracle, nc, P, pseudorandom, imbalanced, micro, monkeypatch):
     monkeypatch.setenv("CEDR_HIP_TILE_LEAVES", "8")  # several stages even on small trees
-    monkeypatch.setenv("CEDR_HIP_MICRO", micro)
+    monkeypatch.setenv("CEDR_HIP_MICRO", "0" if micro == "0" else "1")
+    if micro.startswith("cut"):
+        monkeypatch.setenv("CEDR_HIP_MICRO_CUT", micro[3:])
     trs = R.tracers_vector()[:12]  # all six problem types, two perturbations
     types = [t.problem_type for t in trs]
     v = R.make_values(trs, nc, seed=nc + P)
@@ -80,6 +82,7 @@ def test_plan_invariants(ca, tile):
         for t in st["tiles"]:
             in0, nleaf, out, nint, koff, loff, nlvl = [int(x) for x in t[:7]]
             assert 1 <= nleaf <= tile and nint == nleaf - 1
+            assert int(t[8]) == 1 and st["outs"][int(t[9])] == nleaf + nint - 1  # one output: the root
             covered[in0:in0 + nleaf] += 1
             seen[out] += 1
             kids = st["kids"][koff:koff + nint]
@@ -104,8 +107,10 @@ def test_micro_plan_invariants(ca, imbalanced):
     assert len(st["micro"]) > 0
     covered = np.zeros(nc, np.int32)
     for t in st["tiles"]:
-        in0, nleaf, out, nint, koff, loff, nlvl, moff = [int(x) for x in t]
-        assert 1 <= nleaf <= 64 and nint == nleaf - 1
+        in0, nleaf, out, nint, koff, loff, nlvl, moff, nout, ooff = [int(x) for x in t]
+        assert 1 <= nleaf <= 64 and nint == nleaf - nout and nlvl <= 3  # cut after 3 levels
+        outs = st["outs"][ooff:ooff + nout]
+        assert len(set(outs)) == nout and (outs < nleaf + nint).all()
         prev_end = 0
         for d in st["micro"][moff:moff + nleaf]:
             start, shape = int(d & 0xff), int(d >> 8)

@@ -57,13 +57,15 @@ def test_qlt_config_A(gpu, oracle):
     assert (got >= v.Qm_min).all() and (got <= v.Qm_max).all()
 
 
-@pytest.mark.parametrize("micro", ["0", "1"])
+@pytest.mark.parametrize("micro", ["0", "1", "cut0", "cut1", "cut5"])
 @pytest.mark.parametrize("tile", [2, 3, 16, 128, 256])
 def test_qlt_tile_size_invariance(gpu, oracle, tile, micro, monkeypatch):
     """Results cannot depend on how the tree is cut into tiles (micro tiles or not)."""
     ca = gpu
     monkeypatch.setenv("CEDR_HIP_TILE_LEAVES", str(tile))
-    monkeypatch.setenv("CEDR_HIP_MICRO", micro)
+    monkeypatch.setenv("CEDR_HIP_MICRO", "0" if micro == "0" else "1")
+    if micro.startswith("cut"):
+        monkeypatch.setenv("CEDR_HIP_MICRO_CUT", micro[3:])
     trs = R.tracers_vector()
     v = R.make_values(trs, 333, seed=5)
     want = common.run_oracle_qlt(oracle, (False, True), 333, 1, _types(trs), v)
