@@ -1,0 +1,230 @@
+// C++ drop-in check: a caller written the way the reference's own harness is
+// (cedr_test.cpp + cedr_test_randomized_inl.hpp:12-65), using the C++ classes with
+// the reference's names -- cedr::qlt::QLT<>, cedr::caas::CAAS<>,
+// cedr::tree::make_tree_over_1d_mesh, CDR::DeviceOp copied by value into the
+// caller's own device kernels -- against libcedr_hip.so. Exit code 0 and "PASS"
+// if the property checks of cedr_test_randomized.cpp:293-418 hold.
+//
+//   cedr_test_hip [-nc ncells] [--imbalanced] [--prefer-mass-con]
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <vector>
+
+#include "cedr_caas.hpp"
+#include "cedr_qlt.hpp"
+
+using cedr::Int;
+using cedr::Real;
+typedef cedr::ProblemType PT;
+
+#define HIP_OK(x) do { if ((x) != hipSuccess) { std::printf("HIP error at %s:%d\n", __FILE__, __LINE__); std::exit(2); } } while (0)
+
+// ---- the caller's own device kernels: one thread per (cell) or (tracer, cell)
+template <typename Op> __global__ void k_set_rhom (Op op, int n, const Real* rhom) {
+  const int i = blockIdx.x*blockDim.x + threadIdx.x;
+  if (i < n) op.set_rhom(i, 0, rhom[i]);
+}
+template <typename Op> __global__ void k_set_Qm (Op op, int n, int nt, const Real* Qm, const Real* lo,
+                                                 const Real* hi, const Real* prev) {
+  const int j = blockIdx.x*blockDim.x + threadIdx.x;
+  if (j >= n*nt) return;
+  const int ti = j / n, i = j % n;
+  op.set_Qm(i, ti, Qm[j], lo[j], hi[j], prev[j]);
+}
+template <typename Op> __global__ void k_get_Qm (Op op, int n, int nt, Real* Qm) {
+  const int j = blockIdx.x*blockDim.x + threadIdx.x;
+  if (j >= n*nt) return;
+  Qm[j] = op.get_Qm(j % n, j / n);
+}
+
+struct Tracer { int pt, perturb; bool local_should_hold; };
+
+static Real urand () { return std::rand() / ((Real) RAND_MAX + 1.0); }
+
+struct Values {
+  int n, nt;
+  std::vector<Real> rhom, lo, Qm, hi, prev;  // [tracer][cell]
+  Values (int n_, int nt_) : n(n_), nt(nt_), rhom(n_), lo((size_t) n_*nt_), Qm(lo), hi(lo), prev(lo) {}
+};
+
+static void permute (Real* q, int n) {
+  std::vector<int> p(n);
+  for (int i = 0; i < n; ++i) p[i] = i;
+  for (int i = 0; i < n; ++i) std::swap(p[(int) (urand()*n)], p[(int) (urand()*n)]);
+  std::vector<Real> o(q, q + n);
+  for (int i = 0; i < n; ++i) q[i] = o[p[i]];
+}
+
+// Inputs and perturbations in the manner of cedr_test_randomized.cpp:55-197.
+static void generate (const std::vector<Tracer>& ts, Values& v) {
+  const int n = v.n;
+  for (int i = 0; i < n; ++i) v.rhom[i] = 0.5*(1 + urand());
+  for (size_t t = 0; t < ts.size(); ++t) {
+    Real* lo = &v.lo[t*n], * Qm = &v.Qm[t*n], * hi = &v.hi[t*n], * prev = &v.prev[t*n];
+    const bool nn = ts[t].pt & PT::nonnegative;
+    for (int i = 0; i < n; ++i) {
+      if (nn) {
+        Qm[i] = ts[t].perturb == 0 ? urand() : ((i % 2 == 0) ? 0.75 : -0.75) + urand();
+        lo[i] = 0; hi[i] = 10;
+      } else {
+        const Real qmin = -0.75 + urand(), qmax = qmin + urand(), q = qmin + (qmax - qmin)*urand();
+        lo[i] = qmin*v.rhom[i]; hi[i] = qmax*v.rhom[i];
+        Qm[i] = std::max(lo[i], std::min(hi[i], q*v.rhom[i]));
+      }
+      prev[i] = Qm[i];
+    }
+    const int p = ts[t].perturb;
+    if (p == 1) permute(Qm, n);
+    if (p >= 2) {
+      const bool safety = p >= 4, cm = ! (ts[t].pt & PT::conserve);
+      const Real alpha = (p % 2 == 0) ? 0.5 : 1 - n*std::numeric_limits<Real>::epsilon();
+      Real srho = 0, sQ = 0, smax = 0, qsafe = hi[0]/v.rhom[0];
+      for (int i = 0; i < n; ++i) {
+        srho += v.rhom[i]; sQ += Qm[i]; smax += hi[i];
+        qsafe = std::max(qsafe, hi[i]/v.rhom[i]);
+      }
+      const Real msafe = qsafe*srho;
+      const Real dQ = safety ? ((smax - sQ) + alpha*(msafe - smax))/n : alpha*(smax - sQ)/n;
+      for (int i = 0; i < n; ++i) Qm[i] += dQ;
+      permute(Qm, n);
+      const Real relax = 0.9;
+      const Real dprev = cm ? dQ : (safety ? ((smax - sQ) + relax*alpha*(msafe - smax))/n
+                                           : relax*alpha*(smax - sQ)/n);
+      for (int i = 0; i < n; ++i) prev[i] += dprev;
+    }
+  }
+}
+
+// Property checks in the manner of cedr_test_randomized.cpp:293-418.
+static int check (const char* name, const std::vector<Tracer>& ts, const Values& v,
+                  const std::vector<Real>& out, bool prefer) {
+  const Real eps = std::numeric_limits<Real>::epsilon();
+  const Real lv_tol = prefer ? 100*eps : 0, safety_tol = prefer ? 100*eps : 3*eps;
+  int nerr = 0;
+  const int n = v.n;
+  for (size_t t = 0; t < ts.size(); ++t) {
+    const Real* lo = &v.lo[t*n], * hi = &v.hi[t*n], * prev = &v.prev[t*n], * Qm = &out[t*n];
+    const bool nn = ts[t].pt & PT::nonnegative, safe_only = ! ts[t].local_should_hold;
+    Real qmin = 1e3, qmax = -1e3, m0 = 0, m1 = 0, den = 0;
+    int bad = 0;
+    for (int i = 0; i < n; ++i) {
+      const bool lv = nn ? Qm[i] < 0 : (Qm[i] < lo[i] - lv_tol || Qm[i] > hi[i] + lv_tol);
+      if ( ! safe_only && lv) ++bad;
+      if (ts[t].perturb == 0 && Qm[i] != prev[i]) ++bad;
+      m0 += prev[i]; m1 += Qm[i]; den += std::abs(prev[i]);
+      qmin = std::min(qmin, lo[i]/v.rhom[i]); qmax = std::max(qmax, hi[i]/v.rhom[i]);
+    }
+    if (safe_only) {
+      if (nn) qmin = 0;
+      const Real delta = (qmax - qmin)*safety_tol;
+      for (int i = 0; i < n; ++i)
+        if (nn ? Qm[i] < -3*eps : (Qm[i] < qmin*v.rhom[i] - delta || Qm[i] > qmax*v.rhom[i] + delta)) ++bad;
+    }
+    if (std::abs(m1 - m0)/den > 100*eps) ++bad;
+    if (bad) std::printf("FAIL %s: tracer %zu (type %d, perturbation %d): %d violations\n", name, t,
+                         ts[t].pt, ts[t].perturb, bad);
+    nerr += bad;
+  }
+  return nerr;
+}
+
+template <typename CDRT>
+static int drive (const char* name, CDRT& cdr, const std::vector<Tracer>& ts, int n, bool external_memory,
+                  bool prefer) {
+  const int nt = (int) ts.size();
+  for (const auto& t : ts) cdr.declare_tracer(t.pt, 0);
+  cdr.end_tracer_declarations();
+  Real* b1 = nullptr, * b2 = nullptr;
+  if (external_memory) {
+    size_t s1, s2;
+    cdr.get_buffers_sizes(s1, s2);
+    HIP_OK(hipMalloc((void**) &b1, s1*sizeof(Real)));
+    HIP_OK(hipMalloc((void**) &b2, s2*sizeof(Real)));
+    cdr.set_buffers(b1, b2);
+  }
+  cdr.finish_setup();
+  Values v(n, nt);
+  generate(ts, v);
+  Real* d[6];
+  const size_t N = (size_t) n*nt*sizeof(Real);
+  HIP_OK(hipMalloc((void**) &d[0], n*sizeof(Real)));
+  for (int k = 1; k < 6; ++k) HIP_OK(hipMalloc((void**) &d[k], N));
+  HIP_OK(hipMemcpy(d[0], v.rhom.data(), n*sizeof(Real), hipMemcpyHostToDevice));
+  const Real* src[] = {v.Qm.data(), v.lo.data(), v.hi.data(), v.prev.data()};
+  for (int k = 0; k < 4; ++k) HIP_OK(hipMemcpy(d[k+1], src[k], N, hipMemcpyHostToDevice));
+  const auto op = cdr.get_device_op();  // by value into the kernels below
+  const int B = 256;
+  k_set_rhom<<<(n + B - 1)/B, B>>>(op, n, d[0]);
+  for (int trial = 0; trial < 2; ++trial) {  // the second run repeats the first
+    k_set_Qm<<<(n*nt + B - 1)/B, B>>>(op, n, nt, d[1], d[2], d[3], d[4]);
+    cdr.run();
+  }
+  k_get_Qm<<<(n*nt + B - 1)/B, B>>>(op, n, nt, d[5]);
+  HIP_OK(hipDeviceSynchronize());
+  std::vector<Real> out((size_t) n*nt);
+  HIP_OK(hipMemcpy(out.data(), d[5], N, hipMemcpyDeviceToHost));
+  for (int k = 0; k < 6; ++k) (void) hipFree(d[k]);
+  const int nerr = check(name, ts, v, out, prefer);
+  if (b1) { (void) hipFree(b1); (void) hipFree(b2); }
+  return nerr;
+}
+
+int main (int argc, char** argv) {
+  int ncells = 777;
+  bool imbalanced = false, prefer = false;
+  for (int i = 1; i < argc; ++i) {
+    if ( ! std::strcmp(argv[i], "-nc") && i + 1 < argc) ncells = std::atoi(argv[++i]);
+    else if ( ! std::strcmp(argv[i], "--imbalanced")) imbalanced = true;
+    else if ( ! std::strcmp(argv[i], "--prefer-mass-con")) prefer = true;
+  }
+  std::srand(0);
+  int nerr = 0;
+  try {
+    auto p = cedr::mpi::make_parallel();
+    // cedr_test_randomized.cpp:26-51: 6 perturbations x 6 problem types
+    const int pts[] = { PT::conserve | PT::shapepreserve | PT::consistent, PT::shapepreserve,
+                        PT::conserve | PT::consistent, PT::consistent, PT::nonnegative,
+                        PT::nonnegative | PT::conserve };
+    std::vector<Tracer> ts, cts;
+    for (int perturb = 0; perturb < 6; ++perturb)
+      for (int pt : pts) {
+        const bool lsh = perturb < 4 && ((pt & PT::shapepreserve) || (pt & PT::nonnegative));
+        ts.push_back(Tracer{pt, perturb, lsh});
+        if ((pt & PT::shapepreserve) && lsh) cts.push_back(Tracer{pt, perturb, lsh});  // cedr_caas.cpp:338-351
+      }
+    {
+      cedr::tree::Node::Ptr tree = cedr::tree::make_tree_over_1d_mesh(p, ncells, imbalanced);
+      cedr::CDR::Options o;
+      o.prefer_numerical_mass_conservation_to_numerical_bounds = prefer;
+      cedr::qlt::QLT<> qlt(p, ncells, tree, o);
+      tree = nullptr;  // the caller may drop its tree (cedr_tree.cpp:478)
+      if (qlt.nlclcells() != ncells) { std::printf("FAIL nlclcells\n"); ++nerr; }
+      std::vector<cedr::Long> gcis;
+      qlt.get_owned_glblcells(gcis);
+      for (int i = 0; i < ncells; ++i) if (qlt.gci2lci((Int) gcis[i]) != i) ++nerr;
+      nerr += drive("QLT", qlt, ts, ncells, imbalanced, prefer);
+      for (size_t i = 0; i < ts.size(); ++i) {  // canonical types, cedr_qlt.cpp:707-716
+        const int pt = qlt.get_problem_type((Int) i);
+        if (pt != ((ts[i].pt | PT::consistent) & ~PT::nonnegative) &&
+            pt != ((ts[i].pt | PT::nonnegative) & ~PT::consistent)) ++nerr;
+      }
+    }
+    {
+      cedr::caas::CAAS<> caas(p, ncells);
+      nerr += drive("CAAS", caas, cts, ncells, imbalanced, false);
+    }
+    bool threw = false;  // error convention: std::logic_error (cedr_util.hpp:70-77)
+    try { cedr::caas::CAAS<> bad(p, 0); } catch (const std::logic_error&) { threw = true; }
+    if ( ! threw) { std::printf("FAIL: CAAS with 0 cells did not throw\n"); ++nerr; }
+  } catch (const std::exception& e) {
+    std::printf("exception: %s\n", e.what());
+    return 2;
+  }
+  std::printf(nerr ? "FAIL\n" : "PASS\n");
+  return nerr ? 1 : 0;
+}
