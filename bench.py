@@ -257,11 +257,22 @@ def main():
             gbs = alg[(name, aux)] / (avg_ms * 1e-3) / 1e9
             e.update(algorithmic_bytes=alg[(name, aux)], achieved_GBs=gbs, frac=gbs / HBM_PEAK_GBS)
         kernels.append(e)
+    # HBM traffic per launch from the PMC counters of a profiling run of this same
+    # command (profiles/r01_traffic.json, made by tools/profile_traffic.sh).
+    try:
+        tr = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+        if world == 1 and tr["config"] == {"ncells": ncells, "ntracers": nt}:
+            for k in kernels:
+                t = tr["kernels"].get(k["kernel"])
+                if t and "algorithmic_bytes" in k:
+                    k["traffic"] = t["hbm_bytes"]
+    except (OSError, ValueError, KeyError):
+        pass
     dom = next((k for k in kernels if "achieved_GBs" in k), None)
     roofline = None
     if dom:
         roofline = dict(bound="hbm", kernel=dom["kernel"], achieved=dom["achieved_GBs"],
-                        peak=HBM_PEAK_GBS, unit="GB/s", frac=dom["frac"], traffic=None,
+                        peak=HBM_PEAK_GBS, unit="GB/s", frac=dom["frac"], traffic=dom.get("traffic"),
                         avg_ms=dom["avg_ms"], algorithmic_bytes_per_launch=dom["algorithmic_bytes"])
 
     ok = None
