@@ -301,6 +301,35 @@ void qlt_down_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st,
 // tree levels from the barrier-separated LDS phases.
 struct Micro { int start, shape, size; };
 
+// 16-byte access at 8-byte alignment (gfx950 global memory allows it): one
+// dwordx4 instruction instead of two dwordx2. The vector-memory pipe's cost is
+// per instruction, so halving the instruction count is what matters.
+struct __attribute__((packed, aligned(8))) Pair { double x, y; };
+
+// Cells a, b, c of a micro-subtree from a field row: b rides with a in one load.
+__device__ __forceinline__ void load_cells (const double* __restrict__ p, const int size,
+                                            double& a, double& b, double& c) {
+  a = b = c = 0.0;
+  if (size >= 2) {
+    const Pair ab = *reinterpret_cast<const Pair*>(p);
+    a = ab.x; b = ab.y;
+  } else if (size == 1) {
+    a = p[0];
+  }
+  if (size > 2) c = p[2];
+}
+
+__device__ __forceinline__ void store_cells (double* __restrict__ p, const int size,
+                                             const double a, const double b, const double c) {
+  if (size >= 2) {
+    Pair ab; ab.x = a; ab.y = b;
+    *reinterpret_cast<Pair*>(p) = ab;
+  } else if (size == 1) {
+    p[0] = a;
+  }
+  if (size > 2) p[2] = c;
+}
+
 __device__ __forceinline__ Micro get_micro (const cedr_hip_stage& st, const cedr_hip_tile& tile,
                                             const int lane) {
   Micro m{0, -1, 0};
@@ -352,9 +381,8 @@ void tree_up_micro_kernel (const cedr_hip_stage st, const int nfields,
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
       const int f = c*FT + wave + kNW*r;
-#pragma unroll
-      for (int k = 0; k < 3; ++k)
-        buf[r][k] = (f < nfields && k < m.size) ? src0[static_cast<size_t>(f)*stride + k] : 0.0;
+      load_cells(src0 + static_cast<size_t>(f)*stride, f < nfields ? m.size : 0,
+                 buf[r][0], buf[r][1], buf[r][2]);
     }
   };
 
@@ -440,18 +468,15 @@ void qlt_down_micro_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st
       field = L.bidx_l2r[bi] + (sp ? 0 : ((pt & CONSISTENT) ? 1 : 0));
     }
     const double* __restrict__ s0 = l2r + static_cast<size_t>(field)*S + cell0;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const bool in = bi < nt && k < m.size;
-      if (sp) {
-        buf[k][0] = in ? s0[k] : 0.0;
-        buf[k][1] = in ? s0[S + k] : 0.0;
-        buf[k][2] = in ? s0[2*S + k] : 0.0;
-      } else {
-        buf[k][0] = 0.0;
-        buf[k][1] = in ? s0[k] : 0.0;
-        buf[k][2] = 0.0;
-      }
+    const int sz = bi < nt ? m.size : 0;
+    if (sp) {
+      load_cells(s0, sz, buf[0][0], buf[1][0], buf[2][0]);
+      load_cells(s0 + S, sz, buf[0][1], buf[1][1], buf[2][1]);
+      load_cells(s0 + 2*S, sz, buf[0][2], buf[1][2], buf[2][2]);
+    } else {
+      load_cells(s0, sz, buf[0][1], buf[1][1], buf[2][1]);
+      buf[0][0] = buf[1][0] = buf[2][0] = 0.0;
+      buf[0][2] = buf[1][2] = buf[2][2] = 0.0;
     }
   };
 
@@ -463,10 +488,10 @@ void qlt_down_micro_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st
   double rr;
   KidRho ka, kb, kc, kt;
   {
-    const double* __restrict__ src = l2r + cell0;
-    ka.rh = m.size > 0 ? src[0] : 1.0;
-    kb.rh = m.size > 1 ? src[1] : 1.0;
-    kc.rh = m.size > 2 ? src[2] : 1.0;
+    load_cells(l2r + cell0, m.size, ka.rh, kb.rh, kc.rh);
+    if (m.size < 1) ka.rh = 1.0;
+    if (m.size < 2) kb.rh = 1.0;
+    if (m.size < 3) kc.rh = 1.0;
     kt.rh = (m.shape == 3 ? kb.rh : ka.rh) + (m.shape == 3 ? kc.rh : kb.rh);
     rr = m.shape <= 0 ? ka.rh : (m.shape == 1 ? kt.rh : (m.shape == 2 ? kt.rh + kc.rh : ka.rh + kt.rh));
     ka.w = 1.0/ka.rh; ka.q = 1.0/ka.w;
@@ -622,9 +647,7 @@ void qlt_down_micro_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st
         if (s2) { Xa = x0; Xb = x1; } else { Xb = x0; Xc = x1; }
       }
       double* __restrict__ dst = r2l + static_cast<size_t>(rbw)*S + cell0;
-      dst[0] = Xa;
-      if (m.size > 1) dst[1] = Xb;
-      if (m.size > 2) dst[2] = Xc;
+      store_cells(dst, m.size, Xa, Xb, Xc);
       if (t_onlyw) {
         double* __restrict__ l0p = l2r + static_cast<size_t>(L.bidx_l2r[biw])*S + cell0;
         for (int k = 0; k < m.size; ++k) {
