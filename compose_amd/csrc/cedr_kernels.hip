@@ -8,6 +8,7 @@
 
 #include <cfloat>
 #include <cstdint>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/cedr_hip.h"
@@ -427,6 +428,60 @@ void tree_up_micro_kernel (const cedr_hip_stage st, const int nfields,
   }
 }
 
+// The two node problems of a micro-subtree, in registers. TONLY (a tracer that
+// carries the global q bounds instead of its cells' own) is a compile-time flag,
+// so the common tracer types carry no per-lane selects for that case; callers
+// branch on it wave-uniformly.
+template <bool TONLY>
+__device__ __forceinline__
+void micro_solves (const int shape, const int pt, const double rr, const KidRho ka, const KidRho kb,
+                   const KidRho kc, const KidRho kt, const double (&cur)[3][3], const double (&T)[3],
+                   const double (&RR)[3], const double Xr, const double qlw, const double qhw,
+                   const bool prefer, double& Xa, double& Xb, double& Xc) {
+  double Xt = 0;
+#define CEDR_LO(x) (TONLY ? qlw : (x))
+#define CEDR_HI(x) (TONLY ? qhw : (x))
+  if (shape >= 1) {
+    // root -> (k0, k1): shape 1 (a,b); 2 (t,c); 3 (a,t)
+    const bool s2 = shape == 2, s1 = shape == 1;
+    const KidRho r0 = s2 ? kt : ka;
+    const KidRho r1 = s1 ? kb : (s2 ? kc : kt);
+    const double l0 = s2 ? T[0] : cur[0][0], o0 = s2 ? T[1] : cur[0][1], h0 = s2 ? T[2] : cur[0][2];
+    const double l1 = s1 ? cur[1][0] : (s2 ? cur[2][0] : T[0]);
+    const double o1 = s1 ? cur[1][1] : (s2 ? cur[2][1] : T[1]);
+    const double h1 = s1 ? cur[1][2] : (s2 ? cur[2][2] : T[2]);
+    double x0, x1;
+    solve_node(pt, rr, CEDR_LO(RR[0]), RR[1], CEDR_HI(RR[2]), Xr, r0, CEDR_LO(l0), o0, CEDR_HI(h0),
+               r1, CEDR_LO(l1), o1, CEDR_HI(h1), x0, x1, prefer);
+    if (s2) Xt = x0; else Xa = x0;
+    if (s1) Xb = x1; else if (s2) Xc = x1; else Xt = x1;
+  }
+  if (shape >= 2) {
+    // t -> shape 2 (a,b); 3 (b,c)
+    const bool s2 = shape == 2;
+    const KidRho r0 = s2 ? ka : kb;
+    const KidRho r1 = s2 ? kb : kc;
+    double x0, x1;
+    solve_node(pt, kt.rh, CEDR_LO(T[0]), T[1], CEDR_HI(T[2]), Xt,
+               r0, CEDR_LO(s2 ? cur[0][0] : cur[1][0]), s2 ? cur[0][1] : cur[1][1],
+               CEDR_HI(s2 ? cur[0][2] : cur[1][2]),
+               r1, CEDR_LO(s2 ? cur[1][0] : cur[2][0]), s2 ? cur[1][1] : cur[2][1],
+               CEDR_HI(s2 ? cur[1][2] : cur[2][2]), x0, x1, prefer);
+    if (s2) { Xa = x0; Xb = x1; } else { Xb = x0; Xc = x1; }
+  }
+#undef CEDR_LO
+#undef CEDR_HI
+}
+
+#ifdef CEDR_STAMPS
+// Diagnostic build only: per-phase shader-clock totals of the micro down kernel.
+__device__ unsigned long long g_stamps[64];
+# define STAMP(i) do { const unsigned long long _t = __builtin_amdgcn_s_memtime(); \
+    __builtin_amdgcn_s_waitcnt(0xC07F); acc[i] += _t - t_prev; t_prev = _t; } while (0)
+#else
+# define STAMP(i)
+#endif
+
 // Root -> leaves over micro tiles. 4 tracers per chunk, one per wave for the
 // register part; the LDS part spreads (node, tracer) items over all threads.
 #ifndef CEDR_MICRO_PREFETCH
@@ -480,6 +535,11 @@ void qlt_down_micro_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st
     }
   };
 
+#ifdef CEDR_STAMPS
+  unsigned long long acc[8] = {0,0,0,0,0,0,0,0};
+  unsigned long long t_prev = __builtin_amdgcn_s_memtime();
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+#endif
   double cur[3][3];  // [cell a,b,c][lo, orig, hi]
   load(blockIdx.y*TT + wave, cur);
 
@@ -518,6 +578,7 @@ void qlt_down_micro_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st
   const int tt = threadIdx.x & (TT - 1);  // tracer of this thread in the LDS phases
   double* const R = recs + tt*pitch;      // its record row
   double* const Rw = recs + wave*pitch;   // record row of this wave's tracer
+  STAMP(0);  // tile setup (rho, meta)
 
   for (int c = blockIdx.y; c < nchunks; c += gridDim.y) {
 #if CEDR_MICRO_PREFETCH
@@ -544,6 +605,7 @@ void qlt_down_micro_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st
         (m.shape == 1 ? T[f] : (m.shape == 2 ? T[f] + cur[2][f] : cur[0][f] + T[f]));
     }
     if (lane < nleaf) { Rw[4*lane] = RR[0]; Rw[4*lane+1] = RR[1]; Rw[4*lane+2] = RR[2]; }
+    STAMP(1);  // loads arrived + micro sums
 
     // ---- the LDS phases' tracer of this thread
     const int bi = c*TT + tt;
@@ -559,7 +621,13 @@ void qlt_down_micro_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st
         qhi = r2l[static_cast<size_t>(rb + 2)*S + tile.out];
       }
     }
+    // This thread's output mass (tiles have at most kBlock/TT = 64 outputs),
+    // requested now so that its latency is covered by phase A.
+    const int kout = threadIdx.x >> Log2<TT>::value;
+    double Xout = 0;
+    if (live && kout < tile.nout) Xout = r2l[static_cast<size_t>(rb)*S + tile.out + kout];
     __syncthreads();  // also orders rho/rw/rq before their first use
+    STAMP(2);  // first barrier
     for (int lv = 0; lv < tile.nlvl; ++lv) {
       const int a = lvlL[lv];
       const int nitems = (lvlL[lv+1] - a) << Log2<TT>::value;
@@ -574,10 +642,9 @@ void qlt_down_micro_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st
       }
       __syncthreads();
     }
-    if (live)
-      for (int k = threadIdx.x >> Log2<TT>::value; k < tile.nout; k += kBlock/TT)
-        R[4*st.outs[tile.outs_off + k] + 3] = r2l[static_cast<size_t>(rb)*S + tile.out + k];
+    if (live && kout < tile.nout) R[4*st.outs[tile.outs_off + kout] + 3] = Xout;
     __syncthreads();
+    STAMP(3);  // phase A + outputs' masses
     for (int lv = tile.nlvl - 1; lv >= 0; --lv) {
       const int a = lvlL[lv];
       const int nitems = (lvlL[lv+1] - a) << Log2<TT>::value;
@@ -602,6 +669,7 @@ void qlt_down_micro_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st
       __syncthreads();
     }
 
+    STAMP(4);  // phase B
     // ---- this wave's tracer again: node problems of the micro-subtree in
     // registers, then the cells' masses to HBM.
     if (livew && lane < nleaf) {
@@ -612,40 +680,11 @@ void qlt_down_micro_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st
         qhw = r2l[static_cast<size_t>(rbw + 2)*S + tile.out];
       }
       const double Xr = Rw[4*lane + 3];
-      double Xa = Xr, Xb = 0, Xc = 0, Xt = 0;
-      // bounds seen by the node problems: the cells' own, or the global q bounds
-      auto lo = [&] (const double x) { return t_onlyw ? qlw : x; };
-      auto hi = [&] (const double x) { return t_onlyw ? qhw : x; };
-      if (m.shape >= 1) {
-        // root -> (k0, k1): shape 1 (a,b); 2 (t,c); 3 (a,t)
-        const bool s2 = m.shape == 2, s1 = m.shape == 1;
-        const KidRho r0 = s2 ? kt : ka;
-        const KidRho r1 = s1 ? kb : (s2 ? kc : kt);
-        const double l0 = s2 ? T[0] : cur[0][0], o0 = s2 ? T[1] : cur[0][1], h0 = s2 ? T[2] : cur[0][2];
-        const double l1 = s1 ? cur[1][0] : (s2 ? cur[2][0] : T[0]);
-        const double o1 = s1 ? cur[1][1] : (s2 ? cur[2][1] : T[1]);
-        const double h1 = s1 ? cur[1][2] : (s2 ? cur[2][2] : T[2]);
-        double x0, x1;
-        solve_node(ptw, rr, lo(RR[0]), RR[1], hi(RR[2]), Xr, r0, lo(l0), o0, hi(h0),
-                   r1, lo(l1), o1, hi(h1), x0, x1, prefer);
-        if (s2) Xt = x0; else Xa = x0;
-        if (s1) Xb = x1; else if (s2) Xc = x1; else Xt = x1;
-      }
-      if (m.shape >= 2) {
-        // t -> shape 2 (a,b); 3 (b,c)
-        const bool s2 = m.shape == 2;
-        const KidRho r0 = s2 ? ka : kb;
-        const KidRho r1 = s2 ? kb : kc;
-        const int i0 = s2 ? 0 : 1;
-        double x0, x1;
-        solve_node(ptw, kt.rh, lo(T[0]), T[1], hi(T[2]), Xt,
-                   r0, lo(s2 ? cur[0][0] : cur[1][0]), s2 ? cur[0][1] : cur[1][1],
-                   hi(s2 ? cur[0][2] : cur[1][2]),
-                   r1, lo(s2 ? cur[1][0] : cur[2][0]), s2 ? cur[1][1] : cur[2][1],
-                   hi(s2 ? cur[1][2] : cur[2][2]), x0, x1, prefer);
-        (void) i0;
-        if (s2) { Xa = x0; Xb = x1; } else { Xb = x0; Xc = x1; }
-      }
+      double Xa = Xr, Xb = 0, Xc = 0;
+      if (t_onlyw)
+        micro_solves<true>(m.shape, ptw, rr, ka, kb, kc, kt, cur, T, RR, Xr, qlw, qhw, prefer, Xa, Xb, Xc);
+      else
+        micro_solves<false>(m.shape, ptw, rr, ka, kb, kc, kt, cur, T, RR, Xr, qlw, qhw, prefer, Xa, Xb, Xc);
       double* __restrict__ dst = r2l + static_cast<size_t>(rbw)*S + cell0;
       store_cells(dst, m.size, Xa, Xb, Xc);
       if (t_onlyw) {
@@ -661,7 +700,12 @@ void qlt_down_micro_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st
 #pragma unroll
       for (int f = 0; f < 3; ++f) cur[k][f] = nxt[k][f];
 #endif
+    STAMP(5);  // register node problems + stores issued
   }
+#ifdef CEDR_STAMPS
+  if (lane == 0)
+    for (int i = 0; i < 6; ++i) atomicAdd(&g_stamps[wave*8 + i], acc[i]);
+#endif
 }
 
 // reference cedr_qlt.cpp:453-473 (root_compute), one thread per bulk index.
@@ -1209,6 +1253,17 @@ int cedr_hip_profile_get (int i, int* id, int64_t* aux, float* ms) {
   *aux = r.aux;
   return static_cast<int>(hipEventElapsedTime(ms, r.a, r.b));
 }
+
+#ifdef CEDR_STAMPS
+int cedr_hip_debug_stamps (unsigned long long* out, int reset) {
+  int e = static_cast<int>(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long)*64));
+  if (reset) {
+    unsigned long long z[64] = {0};
+    e |= static_cast<int>(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z)));
+  }
+  return e;
+}
+#endif
 
 const char* cedr_hip_profile_name (int id) {
   return (id >= 0 && id < K_COUNT) ? kKernelNames[id] : "";
