@@ -133,9 +133,11 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo", rank=rank, world_size=world)
         if a.comm == "rccl":
-            uid = [ca.Parallel.rccl_unique_id() if rank == 0 else None]
+            # One communicator per CDR: their collectives run on different streams.
+            uid = [[ca.Parallel.rccl_unique_id(), ca.Parallel.rccl_unique_id()] if rank == 0 else None]
             dist.broadcast_object_list(uid, src=0)
-            par = ca.Parallel.rccl(uid[0], rank, world)
+            par = ca.Parallel.rccl(uid[0][0], rank, world)
+            par2 = ca.Parallel.rccl(uid[0][1], rank, world)
         else:
             def ag_host(x):
                 bufs = [torch.zeros(len(x), dtype=torch.float64) for _ in range(world)]
@@ -146,9 +148,9 @@ def main():
                 t = torch.from_numpy(x.copy())
                 dist.all_reduce(t)
                 return t.numpy()
-            par = ca.Parallel.host_staged(rank, world, ag_host, ar_host)
+            par = par2 = ca.Parallel.host_staged(rank, world, ag_host, ar_host)
     else:
-        par = ca.Parallel.self_()
+        par = par2 = ca.Parallel.self_()
 
     ncells, nt = a.ncells, a.ntracers
     tree = ca.Tree.make_1d(ncells, world, False, False)  # contiguous ownership, balanced
@@ -158,7 +160,7 @@ def main():
     qlt.end_tracer_declarations()
     qlt.finish_setup()
     n = qlt.nlclcells()
-    caas = ca.CAAS(par, n)
+    caas = ca.CAAS(par2, n)
     for _ in range(nt):
         caas.declare_tracer(CST, 0)
     caas.end_tracer_declarations()
@@ -174,7 +176,7 @@ def main():
     # QLT and CAAS are independent CDRs: each gets its own HIP stream so that the
     # latency-bound upper stages / collectives of one overlap the streaming kernels of the other.
     streams = None
-    if not a.serial:
+    if not a.serial and not (world > 1 and a.comm == "gloo"):  # host-staged callbacks are not stream ordered
         streams = (torch.cuda.Stream(device=device), torch.cuda.Stream(device=device))
         qlt.set_stream(streams[0].cuda_stream)
         caas.set_stream(streams[1].cuda_stream)

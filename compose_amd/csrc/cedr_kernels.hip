@@ -488,12 +488,16 @@ __device__ unsigned long long g_stamps[64];
 # define CEDR_MICRO_PREFETCH 0
 #endif
 #ifndef CEDR_MICRO_WAVES
-# define CEDR_MICRO_WAVES 4
+# define CEDR_MICRO_WAVES 3
 #endif
+#ifndef CEDR_MICRO_TW
+# define CEDR_MICRO_TW 2  // tracers per wave and chunk in the micro down sweep
+#endif
+template <int TW>
 __global__ __launch_bounds__(kBlock, CEDR_MICRO_WAVES)
 void qlt_down_micro_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st,
                             double* __restrict__ l2r, double* __restrict__ r2l, const int pitch) {
-  constexpr int TT = kNW;
+  constexpr int TT = kNW*TW;  // tracers per chunk: TW per wave for the register part
   extern __shared__ double lds[];
   const cedr_hip_tile tile = st.tiles[blockIdx.x];
   const int MN = st.max_nodes;
@@ -540,8 +544,9 @@ void qlt_down_micro_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st
   unsigned long long t_prev = __builtin_amdgcn_s_memtime();
   __builtin_amdgcn_s_waitcnt(0xC07F);
 #endif
-  double cur[3][3];  // [cell a,b,c][lo, orig, hi]
-  load(blockIdx.y*TT + wave, cur);
+  double cur[TW][3][3];  // [tracer of this wave][cell a,b,c][lo, orig, hi]
+#pragma unroll
+  for (int s = 0; s < TW; ++s) load(blockIdx.y*TT + wave + kNW*s, cur[s]);
 
   // Densities of this lane's micro-subtree: cells a, b, c, the inner pair t and
   // the root, with 1/rhom and 1/(1/rhom) of everything that can be a kid.
@@ -577,34 +582,28 @@ void qlt_down_micro_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st
   }
   const int tt = threadIdx.x & (TT - 1);  // tracer of this thread in the LDS phases
   double* const R = recs + tt*pitch;      // its record row
-  double* const Rw = recs + wave*pitch;   // record row of this wave's tracer
   STAMP(0);  // tile setup (rho, meta)
 
   for (int c = blockIdx.y; c < nchunks; c += gridDim.y) {
-#if CEDR_MICRO_PREFETCH
-    double nxt[3][3];
-    const int cn = c + gridDim.y;
-    if (cn < nchunks) load(cn*TT + wave, nxt);
-#else
-    if (c != static_cast<int>(blockIdx.y)) load(c*TT + wave, cur);
-#endif
-
-    // ---- this wave's tracer: micro-subtree sums in registers, root record to LDS
-    const int biw = c*TT + wave;
-    const bool livew = biw < nt;
-    const int ptw = livew ? L.bidx_prob[biw] : (SHAPEPRESERVE | CONSISTENT);
-    const bool spw = (ptw & SHAPEPRESERVE) != 0;
-    const bool t_onlyw = (ptw & CONSISTENT) && ! spw;
-    double T[3], RR[3];  // inner pair t and micro root: {lo, orig, hi} sums
+    if (c != static_cast<int>(blockIdx.y)) {
 #pragma unroll
-    for (int f = 0; f < 3; ++f) {
-      const double u = m.shape == 3 ? cur[1][f] : cur[0][f];
-      const double vv = m.shape == 3 ? cur[2][f] : cur[1][f];
-      T[f] = u + vv;
-      RR[f] = m.shape <= 0 ? cur[0][f] :
-        (m.shape == 1 ? T[f] : (m.shape == 2 ? T[f] + cur[2][f] : cur[0][f] + T[f]));
+      for (int s = 0; s < TW; ++s) load(c*TT + wave + kNW*s, cur[s]);
     }
-    if (lane < nleaf) { Rw[4*lane] = RR[0]; Rw[4*lane+1] = RR[1]; Rw[4*lane+2] = RR[2]; }
+
+    // ---- this wave's tracers: micro-subtree sums in registers, root records to LDS
+#pragma unroll
+    for (int s = 0; s < TW; ++s) {
+      double* const Rw = recs + (wave + kNW*s)*pitch;
+#pragma unroll
+      for (int f = 0; f < 3; ++f) {
+        const double u = m.shape == 3 ? cur[s][1][f] : cur[s][0][f];
+        const double vv = m.shape == 3 ? cur[s][2][f] : cur[s][1][f];
+        const double t = u + vv;
+        const double r = m.shape <= 0 ? cur[s][0][f] :
+          (m.shape == 1 ? t : (m.shape == 2 ? t + cur[s][2][f] : cur[s][0][f] + t));
+        if (lane < nleaf) Rw[4*lane + f] = r;
+      }
+    }
     STAMP(1);  // loads arrived + micro sums
 
     // ---- the LDS phases' tracer of this thread
@@ -621,11 +620,16 @@ void qlt_down_micro_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st
         qhi = r2l[static_cast<size_t>(rb + 2)*S + tile.out];
       }
     }
-    // This thread's output mass (tiles have at most kBlock/TT = 64 outputs),
-    // requested now so that its latency is covered by phase A.
+    // This thread's output masses (a micro tile has at most 64 outputs),
+    // requested now so that their latency is covered by phase A.
+    constexpr int NO = (kWave*TT + kBlock - 1)/kBlock;
     const int kout = threadIdx.x >> Log2<TT>::value;
-    double Xout = 0;
-    if (live && kout < tile.nout) Xout = r2l[static_cast<size_t>(rb)*S + tile.out + kout];
+    double Xout[NO];
+#pragma unroll
+    for (int i = 0; i < NO; ++i) {
+      const int k = kout + i*(kBlock/TT);
+      Xout[i] = (live && k < tile.nout) ? r2l[static_cast<size_t>(rb)*S + tile.out + k] : 0.0;
+    }
     __syncthreads();  // also orders rho/rw/rq before their first use
     STAMP(2);  // first barrier
     for (int lv = 0; lv < tile.nlvl; ++lv) {
@@ -642,7 +646,11 @@ void qlt_down_micro_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st
       }
       __syncthreads();
     }
-    if (live && kout < tile.nout) R[4*st.outs[tile.outs_off + kout] + 3] = Xout;
+#pragma unroll
+    for (int i = 0; i < NO; ++i) {
+      const int k = kout + i*(kBlock/TT);
+      if (live && k < tile.nout) R[4*st.outs[tile.outs_off + k] + 3] = Xout[i];
+    }
     __syncthreads();
     STAMP(3);  // phase A + outputs' masses
     for (int lv = tile.nlvl - 1; lv >= 0; --lv) {
@@ -670,21 +678,34 @@ void qlt_down_micro_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st
     }
 
     STAMP(4);  // phase B
-    // ---- this wave's tracer again: node problems of the micro-subtree in
+    // ---- this wave's tracers again: node problems of the micro-subtree in
     // registers, then the cells' masses to HBM.
-    if (livew && lane < nleaf) {
-      const int rbw = L.bidx_r2l[biw];
+#pragma unroll
+    for (int s = 0; s < TW; ++s) {
+      const int biw = c*TT + wave + kNW*s;
+      if (biw >= nt || lane >= nleaf) continue;
+      const int ptw = L.bidx_prob[biw], rbw = L.bidx_r2l[biw];
+      const bool t_onlyw = (ptw & CONSISTENT) && ! (ptw & SHAPEPRESERVE);
       double qlw = 0, qhw = 0;
       if (t_onlyw) {
         qlw = r2l[static_cast<size_t>(rbw + 1)*S + tile.out];
         qhw = r2l[static_cast<size_t>(rbw + 2)*S + tile.out];
       }
-      const double Xr = Rw[4*lane + 3];
+      double T[3], RR[3];  // inner pair t and micro root: {lo, orig, hi} sums, re-formed
+#pragma unroll
+      for (int f = 0; f < 3; ++f) {
+        const double u = m.shape == 3 ? cur[s][1][f] : cur[s][0][f];
+        const double vv = m.shape == 3 ? cur[s][2][f] : cur[s][1][f];
+        T[f] = u + vv;
+        RR[f] = m.shape <= 0 ? cur[s][0][f] :
+          (m.shape == 1 ? T[f] : (m.shape == 2 ? T[f] + cur[s][2][f] : cur[s][0][f] + T[f]));
+      }
+      const double Xr = recs[(wave + kNW*s)*pitch + 4*lane + 3];
       double Xa = Xr, Xb = 0, Xc = 0;
       if (t_onlyw)
-        micro_solves<true>(m.shape, ptw, rr, ka, kb, kc, kt, cur, T, RR, Xr, qlw, qhw, prefer, Xa, Xb, Xc);
+        micro_solves<true>(m.shape, ptw, rr, ka, kb, kc, kt, cur[s], T, RR, Xr, qlw, qhw, prefer, Xa, Xb, Xc);
       else
-        micro_solves<false>(m.shape, ptw, rr, ka, kb, kc, kt, cur, T, RR, Xr, qlw, qhw, prefer, Xa, Xb, Xc);
+        micro_solves<false>(m.shape, ptw, rr, ka, kb, kc, kt, cur[s], T, RR, Xr, qlw, qhw, prefer, Xa, Xb, Xc);
       double* __restrict__ dst = r2l + static_cast<size_t>(rbw)*S + cell0;
       store_cells(dst, m.size, Xa, Xb, Xc);
       if (t_onlyw) {
@@ -694,12 +715,6 @@ void qlt_down_micro_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st
         }
       }
     }
-#if CEDR_MICRO_PREFETCH
-#pragma unroll
-    for (int k = 0; k < 3; ++k)
-#pragma unroll
-      for (int f = 0; f < 3; ++f) cur[k][f] = nxt[k][f];
-#endif
     STAMP(5);  // register node problems + stores issued
   }
 #ifdef CEDR_STAMPS
@@ -1087,11 +1102,12 @@ int cedr_hip_qlt_down (const cedr_hip_qlt_layout* lay, const cedr_hip_stage* st,
   const int pitch = pitch_for(4*st->max_nodes);
   if (st->micro) {
     if (st->max_nleaf > kWave) return static_cast<int>(hipErrorInvalidValue);
-    const size_t ldsm = sizeof(double)*(meta_doubles(st) + 3*mn + static_cast<size_t>(kNW)*pitch);
-    int e = set_lds_limit(qlt_down_micro_kernel, ldsm);
+    constexpr int TW = CEDR_MICRO_TW, TTm = kNW*TW;
+    const size_t ldsm = sizeof(double)*(meta_doubles(st) + 3*mn + static_cast<size_t>(TTm)*pitch);
+    int e = set_lds_limit(qlt_down_micro_kernel<TW>, ldsm);
     if (e) return e;
-    const dim3 gridm(st->ntiles, chunk_split(st->ntiles, (lay->nt + kNW - 1)/kNW));
-    hipLaunchKernelGGL(qlt_down_micro_kernel, gridm, dim3(kBlock), ldsm, stream,
+    const dim3 gridm(st->ntiles, chunk_split(st->ntiles, (lay->nt + TTm - 1)/TTm));
+    hipLaunchKernelGGL(qlt_down_micro_kernel<TW>, gridm, dim3(kBlock), ldsm, stream,
                        *lay, *st, l2r, r2l, pitch);
     return launch_status();
   }
