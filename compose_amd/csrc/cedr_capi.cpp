@@ -240,7 +240,7 @@ void* cedr_plan_create (void* tree, int ncells, int my_rank, int nranks, int max
   PlanBox* b = new PlanBox();
   b->owned = plan::build(t, my_rank, nranks, leaf_slot, o);
   b->p = &b->owned;
-  b->stride = (static_cast<int64_t>(b->owned.nslots) + 15)/16*16;
+  b->stride = (static_cast<int64_t>(b->owned.nslots) + 2 + 15)/16*16;
   return b;
   CEDR_CATCH(nullptr)
 }

@@ -51,7 +51,9 @@ TreeEngine::TreeEngine (const mpi::Parallel::Ptr& p, const tree::FlatTree& t,
       leaf_slot[n] = it->second;
     }
   plan_ = plan::build(t, me, p->size(), leaf_slot, opt);
-  stride_ = (static_cast<int64_t>(plan_.nslots) + 15)/16*16;
+  // Rounded up to 16 doubles (128-byte rows) with at least two spare slots per
+  // row: the kernels' 16-byte cell loads may read up to two slots past a tile.
+  stride_ = (static_cast<int64_t>(plan_.nslots) + 2 + 15)/16*16;
 }
 
 void TreeEngine::upload () {

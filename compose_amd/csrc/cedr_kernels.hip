@@ -61,6 +61,9 @@ void tree_up_kernel (const cedr_hip_stage st, const int nfields, const uint8_t* 
   const int nchunks = (nfields + FT - 1)/FT;
   const double* __restrict__ src0 = data + tile.in0;
   constexpr int NR = FT/kNW;  // field rows a wave loads per chunk
+  // Combine rule per field, staged in LDS (see tree_up_micro_kernel).
+  int32_t* const opL = reinterpret_cast<int32_t*>(v + static_cast<size_t>(FT)*pitch);
+  for (int i = threadIdx.x; i < nfields; i += kBlock) opL[i] = op[i];
 
   auto load = [&] (const int c, double (&buf)[NR][NI]) {
 #pragma unroll
@@ -79,13 +82,14 @@ void tree_up_kernel (const cedr_hip_stage st, const int nfields, const uint8_t* 
   stage_tile_meta(st, tile, kidsL, lvlL);
   const int ff = threadIdx.x & (FT - 1);  // this thread's field within a chunk
   double* const vf = v + ff*pitch;
+  __syncthreads();  // opL (and the tile metadata) staged
 
   for (int c = blockIdx.y; c < nchunks; c += gridDim.y) {
     double nxt[NR][NI];
     const int cn = c + gridDim.y;
     if (cn < nchunks) load(cn, nxt);
     const int f = c*FT + ff;
-    const int o = f < nfields ? op[f] : 0;
+    const int o = f < nfields ? opL[f] : 0;
 #pragma unroll
     for (int r = 0; r < NR; ++r)
 #pragma unroll
@@ -115,6 +119,7 @@ void tree_up_kernel (const cedr_hip_stage st, const int nfields, const uint8_t* 
       for (int k = threadIdx.x >> Log2<FT>::value; k < tile.nout; k += kBlock/FT)
         data[static_cast<size_t>(f)*stride + tile.out + k] = vf[st.outs[tile.outs_off + k]];
     __syncthreads();  // the next chunk overwrites v
+    __builtin_amdgcn_sched_barrier(0);  // see tree_up_micro_kernel
 #pragma unroll
     for (int r = 0; r < NR; ++r)
 #pragma unroll
@@ -287,6 +292,7 @@ void qlt_down_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st,
       }
     }
     __syncthreads();  // the next chunk overwrites the records
+    __builtin_amdgcn_sched_barrier(0);  // see tree_up_micro_kernel
 #pragma unroll
     for (int r = 0; r < NR; ++r)
 #pragma unroll
@@ -308,16 +314,20 @@ struct Micro { int start, shape, size; };
 struct __attribute__((packed, aligned(8))) Pair { double x, y; };
 
 // Cells a, b, c of a micro-subtree from a field row: b rides with a in one load.
+// The loads are UNCONDITIONAL (cells beyond 'size' are read and discarded; every
+// field row is followed by at least two slots of padding, see TreeEngine::stride):
+// with no control flow around them the compiler can count them and wait with
+// vmcnt(N) for exactly the loads it needs, instead of vmcnt(0) for all in flight.
 __device__ __forceinline__ void load_cells (const double* __restrict__ p, const int size,
                                             double& a, double& b, double& c) {
-  a = b = c = 0.0;
-  if (size >= 2) {
-    const Pair ab = *reinterpret_cast<const Pair*>(p);
-    a = ab.x; b = ab.y;
-  } else if (size == 1) {
-    a = p[0];
-  }
-  if (size > 2) c = p[2];
+  // Cells beyond 'size' come back as whatever follows in the row; no caller
+  // uses them (the shape decides which cells enter a result), and masking them
+  // here would make the loads' first use immediate, defeating the prefetch.
+  (void) size;
+  const Pair ab = *reinterpret_cast<const Pair*>(p);
+  a = ab.x;
+  b = ab.y;
+  c = p[2];
 }
 
 __device__ __forceinline__ void store_cells (double* __restrict__ p, const int size,
@@ -361,11 +371,29 @@ __device__ __forceinline__ double micro_up (const int shape, const int o, const 
   return shape == 2 ? combine(o, zi, t, c) : combine(o, zi, a, t);
 }
 
+typedef double d2v __attribute__((ext_vector_type(2)));
+
+// Software prefetch with inline asm. hipcc sinks ordinary prefetch loads down
+// to their first use (the loop-carried copy at the end of an iteration), i.e.
+// into the NEXT chunk, where they are waited for at once. asm volatile loads
+// stay where they are written; the matching wait ties the destination registers
+// ("+v") so that no use can be scheduled before it.
+__device__ __forceinline__ void asm_load_cells (d2v& ab, double& c, const double* p) {
+  asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx2 %1, %2, off offset:16"
+               : "=&v"(ab), "=&v"(c) : "v"(p) : "memory");
+}
+#define CEDR_WAIT_VM0_8(A, C) \
+  asm volatile("s_waitcnt vmcnt(0)" \
+               : "+v"(A[0]), "+v"(A[1]), "+v"(A[2]), "+v"(A[3]), "+v"(A[4]), "+v"(A[5]), "+v"(A[6]), \
+                 "+v"(A[7]), "+v"(C[0]), "+v"(C[1]), "+v"(C[2]), "+v"(C[3]), "+v"(C[4]), "+v"(C[5]), \
+                 "+v"(C[6]), "+v"(C[7]) :: "memory")
+
 template <int FT>
 __global__ __launch_bounds__(kBlock)
 void tree_up_micro_kernel (const cedr_hip_stage st, const int nfields,
                            const uint8_t* __restrict__ op, const int64_t stride,
                            double* __restrict__ data, const int zero_init, const int pitch) {
+  static_assert(FT == 8*kNW, "the prefetch wait macro is written for 8 rows per wave");
   extern __shared__ double lds[];
   const cedr_hip_tile tile = st.tiles[blockIdx.x];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & (kWave - 1);
@@ -377,35 +405,45 @@ void tree_up_micro_kernel (const cedr_hip_stage st, const int nfields,
   const Micro m = get_micro(st, tile, lane);
   const double* __restrict__ src0 = data + tile.in0 + m.start;
   constexpr int NR = FT/kNW;
+  // The per-field combine rule and the tile's output node ids, staged in LDS:
+  // any ordinary global load inside the chunk loop would make the chunk wait
+  // (vmcnt is in-order) for the next chunk's prefetch issued just before.
+  int32_t* const opL = reinterpret_cast<int32_t*>(v + static_cast<size_t>(FT)*pitch);
+  int32_t* const outL = opL + nfields;
+  for (int i = threadIdx.x; i < nfields; i += kBlock) opL[i] = op[i];
+  for (int i = threadIdx.x; i < tile.nout; i += kBlock) outL[i] = st.outs[tile.outs_off + i];
 
-  auto load = [&] (const int c, double (&buf)[NR][3]) {
+  // Cells past a micro-subtree's size are loaded and ignored (the shape decides
+  // what enters a result); rows past the last field re-read the last one.
+  auto load = [&] (const int c, d2v (&ab)[NR], double (&cc)[NR]) {
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
-      const int f = c*FT + wave + kNW*r;
-      load_cells(src0 + static_cast<size_t>(f)*stride, f < nfields ? m.size : 0,
-                 buf[r][0], buf[r][1], buf[r][2]);
+      const int f = min(c*FT + wave + kNW*r, nfields - 1);
+      asm_load_cells(ab[r], cc[r], src0 + static_cast<size_t>(f)*stride);
     }
   };
 
-  double cur[NR][3];
-  if (static_cast<int>(blockIdx.y) < nchunks) load(blockIdx.y, cur);
+  d2v cab[NR], nab[NR];
+  double ccc[NR], ncc[NR];
+  load(blockIdx.y, cab, ccc);  // blockIdx.y < nchunks by construction of the grid
   stage_tile_meta(st, tile, kidsL, lvlL);
   const int ff = threadIdx.x & (FT - 1);
   double* const vf = v + ff*pitch;
+  CEDR_WAIT_VM0_8(cab, ccc);
+  __syncthreads();  // opL, outL and the tile metadata staged
 
   for (int c = blockIdx.y; c < nchunks; c += gridDim.y) {
-    double nxt[NR][3];
     const int cn = c + gridDim.y;
-    if (cn < nchunks) load(cn, nxt);
+    load(cn < nchunks ? cn : c, nab, ncc);  // the last chunk re-reads itself: keeps the count static
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
       const int fr = c*FT + wave + kNW*r;
-      const int orow = fr < nfields ? op[fr] : 0;
-      const double val = micro_up(m.shape, orow, zero_init, cur[r][0], cur[r][1], cur[r][2]);
+      const int orow = fr < nfields ? opL[fr] : 0;
+      const double val = micro_up(m.shape, orow, zero_init, cab[r].x, cab[r].y, ccc[r]);
       if (lane < nleaf) v[(wave + kNW*r)*pitch + lane] = val;
     }
     const int f = c*FT + ff;
-    const int o = f < nfields ? op[f] : 0;
+    const int o = f < nfields ? opL[f] : 0;
     __syncthreads();
     for (int lv = 0; lv < tile.nlvl; ++lv) {
       const int a = lvlL[lv];
@@ -419,12 +457,11 @@ void tree_up_micro_kernel (const cedr_hip_stage st, const int nfields,
     }
     if (f < nfields)
       for (int k = threadIdx.x >> Log2<FT>::value; k < tile.nout; k += kBlock/FT)
-        data[static_cast<size_t>(f)*stride + tile.out + k] = vf[st.outs[tile.outs_off + k]];
+        data[static_cast<size_t>(f)*stride + tile.out + k] = vf[outL[k]];
     __syncthreads();
+    CEDR_WAIT_VM0_8(nab, ncc);
 #pragma unroll
-    for (int r = 0; r < NR; ++r)
-#pragma unroll
-      for (int k = 0; k < 3; ++k) cur[r][k] = nxt[r][k];
+    for (int r = 0; r < NR; ++r) { cab[r] = nab[r]; ccc[r] = ncc[r]; }
   }
 }
 
@@ -1070,7 +1107,8 @@ int cedr_hip_tree_up (const cedr_hip_stage* st, int32_t nfields, const uint8_t* 
   if (st->ntiles == 0 || nfields == 0) return 0;
   if (st->max_nleaf > 256) return static_cast<int>(hipErrorInvalidValue);
   const int pitch = pitch_for(st->max_nodes);
-  const size_t lds = sizeof(double)*(meta_doubles(st) + static_cast<size_t>(kUpFT)*pitch);
+  const size_t lds = sizeof(double)*(meta_doubles(st) + static_cast<size_t>(kUpFT)*pitch) +
+    sizeof(int32_t)*static_cast<size_t>(nfields + 2 + kWave);  // + op table, + output node ids
   if (lds > 160*1024) return static_cast<int>(hipErrorInvalidValue);
   const dim3 grid(st->ntiles, chunk_split(st->ntiles, (nfields + kUpFT - 1)/kUpFT));
   if (st->micro) {
