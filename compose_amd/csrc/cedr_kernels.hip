@@ -521,9 +521,6 @@ __device__ unsigned long long g_stamps[64];
 
 // Root -> leaves over micro tiles. 4 tracers per chunk, one per wave for the
 // register part; the LDS part spreads (node, tracer) items over all threads.
-#ifndef CEDR_MICRO_PREFETCH
-# define CEDR_MICRO_PREFETCH 0
-#endif
 #ifndef CEDR_MICRO_WAVES
 # define CEDR_MICRO_WAVES 3
 #endif
