@@ -1,0 +1,95 @@
+"""Parity at the sizes BASELINE.json quotes. Config B (150k x 10) is checked against the
+oracle directly; config C (1.5M x 40) through the size-independent properties of
+cedr_test_randomized.cpp:293-418 (bounds, mass conservation) plus a checksum comparison
+with the oracle on a strided sample of tracers; a 1M-cell x 600-tracer problem puts field
+offsets beyond 2^31 elements (the reference's Int indexing overflows there)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import common
+import randomized as R
+
+pytestmark = pytest.mark.gpu
+CST = 7
+
+
+def _inputs(n, nt, seed):
+    rng = np.random.default_rng(seed)
+    rhom = 0.5 * (1 + rng.random(n))
+    q_min = -0.75 + rng.random((nt, n))
+    q_max = q_min + rng.random((nt, n))
+    q = q_min + (q_max - q_min) * rng.random((nt, n))
+    v = R.Values(nt, n)
+    v.rhom[:] = rhom
+    v.Qm_min[:], v.Qm_max[:] = q_min * rhom, q_max * rhom
+    v.Qm_prev[:] = np.maximum(v.Qm_min, np.minimum(v.Qm_max, q * rhom))
+    for t in range(nt):  # perturbation 1: permute
+        v.Qm[t] = v.Qm_prev[t][rng.permutation(n)]
+    return v
+
+
+def test_config_B_vs_oracle(gpu, oracle):
+    ca = gpu
+    n, nt = 150000, 10
+    v = _inputs(n, nt, 1)
+    q = common.make_hip_qlt(ca, ca.Tree.make_1d(n), n, [CST] * nt)
+    got = common.run_hip_qlt(ca, q, v)
+    want = common.run_oracle_qlt(oracle, (False, False), n, 1, [CST] * nt, v)
+    assert np.array_equal(got, want)
+    cg = common.run_hip_caas(ca, n, [CST] * nt, v)
+    cw, _ = common.run_oracle_caas(oracle, [n], [CST] * nt, v)
+    assert np.abs(cg - cw).max() <= 1e-13 * np.abs(cw).max()
+
+
+def test_config_C_properties(gpu, oracle):
+    ca = gpu
+    n, nt = 1500000, 40
+    v = _inputs(n, nt, 2)
+    q = common.make_hip_qlt(ca, ca.Tree.make_1d(n), n, [CST] * nt)
+    got = common.run_hip_qlt(ca, q, v)
+    assert (got >= v.Qm_min).all() and (got <= v.Qm_max).all()
+    rel = np.abs(got.sum(1) - v.Qm_prev.sum(1)) / np.abs(v.Qm_prev).sum(1)
+    assert rel.max() <= 1e-13
+    # three tracers against the oracle (it runs any tracer subset: tracers are independent)
+    sub = [0, 17, 39]
+    vs = R.Values(len(sub), n)
+    vs.rhom[:] = v.rhom
+    for k, t in enumerate(sub):
+        vs.Qm[k], vs.Qm_min[k], vs.Qm_max[k], vs.Qm_prev[k] = v.Qm[t], v.Qm_min[t], v.Qm_max[t], v.Qm_prev[t]
+    want = common.run_oracle_qlt(oracle, (False, False), n, 1, [CST] * len(sub), vs)
+    assert np.array_equal(got[sub], want)
+    cg = common.run_hip_caas(ca, n, [CST] * nt, v)
+    assert (cg >= v.Qm_min).all() and (cg <= v.Qm_max).all()
+    rel = np.abs(cg.sum(1) - v.Qm_prev.sum(1)) / np.abs(v.Qm_prev).sum(1)
+    assert rel.max() <= 1e-13
+
+
+def test_offsets_beyond_int32(gpu, oracle):
+    """1M cells x 600 identical cst tracers: l2r has 2401 field rows of > 2M slots, i.e. field
+    offsets up to 4.9e9 elements. Every tracer must reproduce tracer 0's oracle result."""
+    ca = gpu
+    L = ca.lib()
+    n, nt = 1000000, 600
+    v = _inputs(n, 1, 3)
+    want = common.run_oracle_qlt(oracle, (False, False), n, 1, [CST], v)[0]
+    q = common.make_hip_qlt(ca, ca.Tree.make_1d(n), n, [CST] * nt)
+    b1, _ = q.get_buffers_sizes()
+    assert b1 > 2**31
+    rows = {k: ca.DeviceArray.from_numpy(a[0]) for k, a in
+            (("Qm", v.Qm), ("lo", v.Qm_min), ("hi", v.Qm_max), ("prev", v.Qm_prev))}
+    big = {k: ca.DeviceArray(n * nt) for k in rows}
+    for k in rows:
+        for t in range(nt):
+            ca._chk(L.cedr_memcpy_d2d_async(big[k].offset(t * n), rows[k].ptr, 8 * n, None))
+    q.set_rhom(ca.DeviceArray.from_numpy(v.rhom))
+    q.set_Qm(big["Qm"], big["lo"], big["hi"], big["prev"])
+    q.run()
+    out = ca.DeviceArray(n * nt)
+    q.get_Qm(out)
+    ca.synchronize()
+    row = np.empty(n)
+    for t in (0, 1, 299, 598, 599):
+        ca._chk(L.cedr_memcpy_d2h(row.ctypes.data, out.offset(t * n), row.nbytes))
+        assert np.array_equal(row, want), t
