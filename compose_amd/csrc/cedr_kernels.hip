@@ -371,6 +371,16 @@ __device__ __forceinline__ double micro_up (const int shape, const int o, const 
   return shape == 2 ? combine(o, zi, t, c) : combine(o, zi, a, t);
 }
 
+#ifdef CEDR_STAMPS
+// Diagnostic build only: per-phase shader-clock totals of the micro kernels
+// (down: slots 0-31, up: slots 32-63).
+__device__ unsigned long long g_stamps[64];
+# define STAMP(i) do { const unsigned long long _t = __builtin_amdgcn_s_memtime(); \
+    __builtin_amdgcn_s_waitcnt(0xC07F); acc[i] += _t - t_prev; t_prev = _t; } while (0)
+#else
+# define STAMP(i)
+#endif
+
 typedef double d2v __attribute__((ext_vector_type(2)));
 
 // Software prefetch with inline asm. hipcc sinks ordinary prefetch loads down
@@ -387,6 +397,16 @@ __device__ __forceinline__ void asm_load_cells (d2v& ab, double& c, const double
                : "+v"(A[0]), "+v"(A[1]), "+v"(A[2]), "+v"(A[3]), "+v"(A[4]), "+v"(A[5]), "+v"(A[6]), \
                  "+v"(A[7]), "+v"(C[0]), "+v"(C[1]), "+v"(C[2]), "+v"(C[3]), "+v"(C[4]), "+v"(C[5]), \
                  "+v"(C[6]), "+v"(C[7]) :: "memory")
+
+// The same for a plain sum (the rule of almost every field): one add for the
+// inner pair, one for the root, operands picked by selects -- no branches.
+// fp addition commutes, so ((a,b),c) and (a,(b,c)) share the second add.
+__device__ __forceinline__ double micro_up_sum (const int shape, const double a, const double b,
+                                                const double c) {
+  const double t = (shape == 3 ? b : a) + (shape == 3 ? c : b);
+  const double r = t + (shape == 2 ? c : a);
+  return shape <= 0 ? a : (shape == 1 ? t : r);
+}
 
 template <int FT>
 __global__ __launch_bounds__(kBlock)
@@ -415,14 +435,21 @@ void tree_up_micro_kernel (const cedr_hip_stage st, const int nfields,
 
   // Cells past a micro-subtree's size are loaded and ignored (the shape decides
   // what enters a result); rows past the last field re-read the last one.
+  const double* const plast = src0 + static_cast<size_t>(nfields - 1)*stride;
   auto load = [&] (const int c, d2v (&ab)[NR], double (&cc)[NR]) {
+    const double* prow = src0 + static_cast<size_t>(c*FT + wave)*stride;
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
-      const int f = min(c*FT + wave + kNW*r, nfields - 1);
-      asm_load_cells(ab[r], cc[r], src0 + static_cast<size_t>(f)*stride);
+      asm_load_cells(ab[r], cc[r], prow <= plast ? prow : plast);
+      prow += static_cast<size_t>(kNW)*stride;
     }
   };
 
+#ifdef CEDR_STAMPS
+  unsigned long long acc[8] = {0,0,0,0,0,0,0,0};
+  unsigned long long t_prev = __builtin_amdgcn_s_memtime();
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+#endif
   d2v cab[NR], nab[NR];
   double ccc[NR], ncc[NR];
   load(blockIdx.y, cab, ccc);  // blockIdx.y < nchunks by construction of the grid
@@ -431,6 +458,7 @@ void tree_up_micro_kernel (const cedr_hip_stage st, const int nfields,
   double* const vf = v + ff*pitch;
   CEDR_WAIT_VM0_8(cab, ccc);
   __syncthreads();  // opL, outL and the tile metadata staged
+  STAMP(0);  // setup + first chunk's loads
 
   for (int c = blockIdx.y; c < nchunks; c += gridDim.y) {
     const int cn = c + gridDim.y;
@@ -439,12 +467,16 @@ void tree_up_micro_kernel (const cedr_hip_stage st, const int nfields,
     for (int r = 0; r < NR; ++r) {
       const int fr = c*FT + wave + kNW*r;
       const int orow = fr < nfields ? opL[fr] : 0;
-      const double val = micro_up(m.shape, orow, zero_init, cab[r].x, cab[r].y, ccc[r]);
+      const double val = (orow == 0 && ! zero_init) ?
+        micro_up_sum(m.shape, cab[r].x, cab[r].y, ccc[r]) :
+        micro_up(m.shape, orow, zero_init, cab[r].x, cab[r].y, ccc[r]);
       if (lane < nleaf) v[(wave + kNW*r)*pitch + lane] = val;
     }
     const int f = c*FT + ff;
     const int o = f < nfields ? opL[f] : 0;
+    STAMP(1);  // issue prefetch + micro combines
     __syncthreads();
+    STAMP(2);  // barrier
     for (int lv = 0; lv < tile.nlvl; ++lv) {
       const int a = lvlL[lv];
       const int nitems = (lvlL[lv+1] - a) << Log2<FT>::value;
@@ -455,14 +487,21 @@ void tree_up_micro_kernel (const cedr_hip_stage st, const int nfields,
       }
       __syncthreads();
     }
+    STAMP(3);  // LDS levels
     if (f < nfields)
       for (int k = threadIdx.x >> Log2<FT>::value; k < tile.nout; k += kBlock/FT)
         data[static_cast<size_t>(f)*stride + tile.out + k] = vf[outL[k]];
     __syncthreads();
+    STAMP(4);  // outputs + barrier
     CEDR_WAIT_VM0_8(nab, ncc);
+    STAMP(5);  // wait for the prefetched chunk
 #pragma unroll
     for (int r = 0; r < NR; ++r) { cab[r] = nab[r]; ccc[r] = ncc[r]; }
   }
+#ifdef CEDR_STAMPS
+  if (lane == 0)
+    for (int i = 0; i < 6; ++i) atomicAdd(&g_stamps[32 + wave*8 + i], acc[i]);
+#endif
 }
 
 // The two node problems of a micro-subtree, in registers. TONLY (a tracer that
@@ -510,14 +549,6 @@ void micro_solves (const int shape, const int pt, const double rr, const KidRho 
 #undef CEDR_HI
 }
 
-#ifdef CEDR_STAMPS
-// Diagnostic build only: per-phase shader-clock totals of the micro down kernel.
-__device__ unsigned long long g_stamps[64];
-# define STAMP(i) do { const unsigned long long _t = __builtin_amdgcn_s_memtime(); \
-    __builtin_amdgcn_s_waitcnt(0xC07F); acc[i] += _t - t_prev; t_prev = _t; } while (0)
-#else
-# define STAMP(i)
-#endif
 
 // Root -> leaves over micro tiles. 4 tracers per chunk, one per wave for the
 // register part; the LDS part spreads (node, tracer) items over all threads.

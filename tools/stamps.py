@@ -20,6 +20,10 @@ q.run(); torch.cuda.synchronize(); L.cedr_hip_debug_stamps(buf, 1)
 for _ in range(3): q.run()
 torch.cuda.synchronize(); L.cedr_hip_debug_stamps(buf, 1)
 names = ["setup", "load+micro sums", "barrier1", "phase A", "phase B", "register solves"]
+unames = ["setup+first loads", "issue prefetch+micro combines", "barrier", "LDS levels", "outputs+barrier", "wait prefetch"]
 for w in range(4):
     tot = sum(buf[w*8+i] for i in range(6))
-    print("wave", w, "total cycles/run/WG %.0f" % (tot/3/8192), " ".join("%s %.1f%%" % (names[i], 100.0*buf[w*8+i]/tot) for i in range(6)))
+    print("down wave", w, "total cycles/run/WG %.0f" % (tot/3/8192), " ".join("%s %.1f%%" % (names[i], 100.0*buf[w*8+i]/tot) for i in range(6)))
+for w in range(4):
+    tot = sum(buf[32+w*8+i] for i in range(6))
+    print("up   wave", w, "total cycles/run/WG %.0f" % (tot/3/8192), " ".join("%s %.1f%%" % (unames[i], 100.0*buf[32+w*8+i]/tot) for i in range(6)))
