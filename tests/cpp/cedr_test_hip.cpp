@@ -9,7 +9,9 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdint>
 #include <cstdio>
+#include <string>
 #include <cstdlib>
 #include <cstring>
 #include <limits>
@@ -44,7 +46,14 @@ template <typename Op> __global__ void k_get_Qm (Op op, int n, int nt, Real* Qm)
 
 struct Tracer { int pt, perturb; bool local_should_hold; };
 
-static Real urand () { return std::rand() / ((Real) RAND_MAX + 1.0); }
+// Uniform in [0,1) on the 2^-31 grid like the reference's rand()/(RAND_MAX+1.0)
+// (cedr_test_randomized.cpp:53), from a private generator: std::rand's state is
+// shared with the HIP runtime's threads, which made the inputs differ run to run.
+static uint64_t g_rng = 0x9E3779B97F4A7C15ull;
+static Real urand () {
+  g_rng = g_rng*6364136223846793005ull + 1442695040888963407ull;
+  return (Real) (g_rng >> 33) / 2147483648.0;
+}
 
 struct Values {
   int n, nt;
@@ -110,12 +119,22 @@ static int check (const char* name, const std::vector<Tracer>& ts, const Values&
   for (size_t t = 0; t < ts.size(); ++t) {
     const Real* lo = &v.lo[t*n], * hi = &v.hi[t*n], * prev = &v.prev[t*n], * Qm = &out[t*n];
     const bool nn = ts[t].pt & PT::nonnegative, safe_only = ! ts[t].local_should_hold;
-    Real qmin = 1e3, qmax = -1e3, m0 = 0, m1 = 0, den = 0;
+    Real qmin = 1e3, qmax = -1e3;
+    // The reference sums the masses in double; at ~1000 cells that sum's own roundoff reaches its
+    // 100 eps tolerance for about one seed in three (oracle included), so sum in extended precision.
+    long double m0 = 0, m1 = 0, den = 0;
     int bad = 0;
     for (int i = 0; i < n; ++i) {
       const bool lv = nn ? Qm[i] < 0 : (Qm[i] < lo[i] - lv_tol || Qm[i] > hi[i] + lv_tol);
-      if ( ! safe_only && lv) ++bad;
-      if (ts[t].perturb == 0 && Qm[i] != prev[i]) ++bad;
+      if ( ! safe_only && lv) {
+        ++bad;
+        std::printf("  %s tracer %zu cell %d: local bound violated: %.17g not in [%.17g, %.17g]\n", name, t, i,
+                    Qm[i], nn ? 0.0 : lo[i], nn ? 1e300 : hi[i]);
+      }
+      if (ts[t].perturb == 0 && Qm[i] != prev[i]) {
+        ++bad;
+        std::printf("  %s tracer %zu cell %d: changed %.17g -> %.17g\n", name, t, i, prev[i], Qm[i]);
+      }
       m0 += prev[i]; m1 += Qm[i]; den += std::abs(prev[i]);
       qmin = std::min(qmin, lo[i]/v.rhom[i]); qmax = std::max(qmax, hi[i]/v.rhom[i]);
     }
@@ -123,9 +142,17 @@ static int check (const char* name, const std::vector<Tracer>& ts, const Values&
       if (nn) qmin = 0;
       const Real delta = (qmax - qmin)*safety_tol;
       for (int i = 0; i < n; ++i)
-        if (nn ? Qm[i] < -3*eps : (Qm[i] < qmin*v.rhom[i] - delta || Qm[i] > qmax*v.rhom[i] + delta)) ++bad;
+        if (nn ? Qm[i] < -3*eps : (Qm[i] < qmin*v.rhom[i] - delta || Qm[i] > qmax*v.rhom[i] + delta)) {
+          ++bad;
+          std::printf("  %s tracer %zu cell %d: safety bound violated: %.17g\n", name, t, i, Qm[i]);
+        }
     }
-    if (std::abs(m1 - m0)/den > 100*eps) ++bad;
+    const Real rd = (Real) (std::fabs(m1 - m0)/den);
+    if ( ! (rd <= 100*eps)) {
+      ++bad;
+      std::printf("  %s tracer %zu: mass %.17g -> %.17g, relative error %.3e\n", name, t, (Real) m0,
+                  (Real) m1, rd);
+    }
     if (bad) std::printf("FAIL %s: tracer %zu (type %d, perturbation %d): %d violations\n", name, t,
                          ts[t].pt, ts[t].perturb, bad);
     nerr += bad;
@@ -169,6 +196,13 @@ static int drive (const char* name, CDRT& cdr, const std::vector<Tracer>& ts, in
   std::vector<Real> out((size_t) n*nt);
   HIP_OK(hipMemcpy(out.data(), d[5], N, hipMemcpyDeviceToHost));
   for (int k = 0; k < 6; ++k) (void) hipFree(d[k]);
+  if (const char* dump = std::getenv("CEDR_TEST_DUMP")) {  // debugging aid: raw results of this run
+    const std::string fn = std::string(dump) + "." + name;
+    if (FILE* fp = std::fopen(fn.c_str(), "wb")) {
+      std::fwrite(out.data(), sizeof(Real), out.size(), fp);
+      std::fclose(fp);
+    }
+  }
   const int nerr = check(name, ts, v, out, prefer);
   if (b1) { (void) hipFree(b1); (void) hipFree(b2); }
   return nerr;
@@ -182,7 +216,6 @@ int main (int argc, char** argv) {
     else if ( ! std::strcmp(argv[i], "--imbalanced")) imbalanced = true;
     else if ( ! std::strcmp(argv[i], "--prefer-mass-con")) prefer = true;
   }
-  std::srand(0);
   int nerr = 0;
   try {
     auto p = cedr::mpi::make_parallel();
