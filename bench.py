@@ -63,8 +63,15 @@ def gen_inputs(torch, n, nt, seed, device):
     del q_min, q_max, q
     # perturbation type 1 (cedr_test_randomized.cpp:109-118): permute Qm within the shard
     Qm = torch.empty_like(Qm_prev)
+    mode = os.environ.get("CEDR_BENCH_PERTURB", "permute")  # diagnostics only
     for t in range(nt):
-        Qm[t] = Qm_prev[t][torch.randperm(n, generator=g, device=device)]
+        if mode == "none":
+            Qm[t] = Qm_prev[t]
+        elif mode == "small":  # mass-neutral nudges that stay inside the bounds almost everywhere
+            d = 1e-3 * (Qm_max[t] - Qm_min[t]) * (torch.rand(n, generator=g, device=device, dtype=f64) - 0.5)
+            Qm[t] = Qm_prev[t] + d - d.roll(1)
+        else:
+            Qm[t] = Qm_prev[t][torch.randperm(n, generator=g, device=device)]
     return rhom, Qm.contiguous(), Qm_min.contiguous(), Qm_max.contiguous(), Qm_prev.contiguous()
 
 

@@ -57,28 +57,40 @@ __device__ void qp_2d (const double w0, const double w1, const double q0, const 
       if ( ! (x1 < lo1 || x1 > hi1)) return;
     }
   }
-  // Line a'x = b as base + alpha*dir, dir = (-1, 1); intersect the box edges.
+  // Line a'x = b as base + alpha*dir, dir = (-1, 1); intersect the box edges:
+  // 0 bottom (x1 = lo1), 1 right (x0 = hi0), 2 top (x1 = hi1), 3 left (x0 = lo0).
+  // The reference scans the four alphas for the FIRST minimum and the FIRST
+  // maximum, takes the two remaining edges in index order (m0 < m1; edges 1, 2
+  // if all four alphas are equal) and keeps the one with the smaller objective,
+  // m0 on a tie. Here the same choice is made without branches or indexed
+  // arrays: the twelve ordered comparisons give wave masks (scalar registers),
+  // everything up to the final selects is scalar mask logic.
   const double base = 0.5*b;
-  double al[4];
-  al[0] = lo1 - base;      // bottom
-  al[1] = -(hi0 - base);   // right
-  al[2] = hi1 - base;      // top
-  al[3] = -(lo0 - base);   // left
-  double mn = al[0], mx = al[0];
-  int imin = 0, imax = 0;
-#pragma unroll
-  for (int i = 1; i < 4; ++i) {
-    if (al[i] < mn) { mn = al[i]; imin = i; }
-    if (al[i] > mx) { mx = al[i]; imax = i; }
-  }
-  int m0 = -1, m1 = -1;
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-    if (i != imin && i != imax) {
-      if (m0 < 0) m0 = i; else if (m1 < 0) m1 = i;
-    }
-  const double a0 = m0 == 0 ? al[0] : m0 == 1 ? al[1] : m0 == 2 ? al[2] : al[3];
-  const double a1 = m1 == 0 ? al[0] : m1 == 1 ? al[1] : m1 == 2 ? al[2] : al[3];
+  const double al0 = lo1 - base;      // bottom
+  const double al1 = -(hi0 - base);   // right
+  const double al2 = hi1 - base;      // top
+  const double al3 = -(lo0 - base);   // left
+  const bool L01 = al0 < al1, L02 = al0 < al2, L03 = al0 < al3;
+  const bool L10 = al1 < al0, L12 = al1 < al2, L13 = al1 < al3;
+  const bool L20 = al2 < al0, L21 = al2 < al1, L23 = al2 < al3;
+  const bool L30 = al3 < al0, L31 = al3 < al1, L32 = al3 < al2;
+  // first minimum: smaller than everything before, not larger than anything after
+  const bool mn0 = ! L10 && ! L20 && ! L30;
+  const bool mn1 = L10 && ! L21 && ! L31;
+  const bool mn2 = L20 && L21 && ! L32;
+  const bool mn3 = L30 && L31 && L32;
+  // first maximum
+  const bool mx0 = ! L01 && ! L02 && ! L03;
+  const bool mx1 = L01 && ! L12 && ! L13;
+  const bool mx2 = L02 && L12 && ! L23;
+  const bool mx3 = L03 && L13 && L23;
+  const bool e0 = mn0 || mx0, e1 = mn1 || mx1, e2 = mn2 || mx2, e3 = mn3 || mx3;
+  // m0: first edge that is neither; m1: second one
+  const bool s00 = ! e0, s01 = e0 && ! e1;                      // else m0 == 2
+  const bool s11 = ! e0 && ! e1, s12 = ! e2 && (e0 != e1);      // else m1 == 3
+  (void) e3;
+  const double a0 = s00 ? al0 : (s01 ? al1 : al2);
+  const double a1 = s11 ? al1 : (s12 ? al2 : al3);
   double obj0, obj1;
   {
     const double t0 = base - a0, t1 = base + a0;
@@ -90,16 +102,20 @@ __device__ void qp_2d (const double w0, const double w1, const double q0, const 
     const double d0 = y0 - t0, d1 = y1 - t1;
     obj1 = 0; obj1 += w0*(d0*d0); obj1 += w1*(d1*d1);
   }
-  const int ai = obj0 <= obj1 ? m0 : m1;
-  if (ai == 0 || ai == 2) {
-    x1 = ai == 0 ? lo1 : hi1;
-    x0 = b - x1;
-    if (clip) x0 = rmin(hi0, rmax(lo0, x0));
-  } else {
-    x0 = ai == 1 ? hi0 : lo0;
-    x1 = b - x0;
-    if (clip) x1 = rmin(hi1, rmax(lo1, x1));
+  const bool pick0 = obj0 <= obj1;
+  // chosen edge ai as masks
+  const bool c0 = pick0 && s00;                                 // ai == 0 (only m0 can be 0)
+  const bool c1 = pick0 ? s01 : s11;                            // ai == 1
+  const bool c2 = pick0 ? (! s00 && ! s01) : (! s11 && s12);    // ai == 2
+  const bool fixed1 = c0 || c2;                                 // x1 sits on its bound, else x0 does
+  const double v = c0 ? lo1 : (c2 ? hi1 : (c1 ? hi0 : lo0));
+  double other = b - v;
+  if (clip) {
+    const double lo_o = fixed1 ? lo0 : lo1, hi_o = fixed1 ? hi0 : hi1;
+    other = rmin(hi_o, rmax(lo_o, other));
   }
+  x0 = fixed1 ? other : v;
+  x1 = fixed1 ? v : other;
 }
 
 // reference cedr_qlt_inl.hpp:69-99 (r2l_nl_adjust_bounds)
