@@ -54,3 +54,18 @@ def test_bench_multiprocess_same_gpu(gpu, nranks):
     line = [l for l in res.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == nranks and d["check_ok"] is True and d["scaling"] == "strong"
+
+
+def test_bench_rccl_failure_falls_back_to_host_staged(gpu):
+    """Two ranks on ONE GPU make ncclCommInitRank fail (duplicate device): bench.py must
+    notice on every rank, switch the collectives to the host-staged transport, still
+    produce correct results, and say which transport it measured."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29507", os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--steps", "2", "--warmup", "1", "--ncells", "30000", "--ntracers", "6",
+           "--comm", "rccl", "--same-gpu", "--check", "--no-cpu-baseline"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert res.returncode == 0, res.stdout[-1500:] + res.stderr[-1500:]
+    d = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["check_ok"] is True
+    assert d["config"]["transport"].startswith("gloo-host-staged (RCCL failed")
