@@ -1145,11 +1145,19 @@ constexpr int kDownTT = 8;   // tracers per chunk, root->leaves
 inline size_t meta_doubles (const cedr_hip_stage* st) { return static_cast<size_t>(st->max_nint) + 1; }
 // smallest p >= n with p == 1 (mod 32)
 inline int pitch_for (int n) { return (n + 30)/32*32 + 1; }
-// Spread the chunks of a stage with few tiles over more workgroups.
-inline int chunk_split (int ntiles, int nchunks) {
-  int y = (1024 + ntiles - 1)/ntiles;
+// Spread the chunks of a stage with few tiles over more workgroups, chunks
+// dealt evenly. 'target' = workgroups wanted: the leaves->root kernels pipeline
+// their loads across the chunks of a workgroup and prefer long loops (one
+// workgroup per CU slot is enough); the root->leaves kernels are limited by the
+// last, partly idle round of workgroups and prefer ~4 rounds (measured at 187 500
+// cells x 40 tracers, the 8-GPU shard: 0.117 -> 0.103 ms).
+constexpr int kSplitUp = 1024, kSplitDown = 3072;  // kSplitDown: micro tiles only
+inline int chunk_split (int ntiles, int nchunks, int target) {
+  int y = (target + ntiles - 1)/ntiles;
   if (y > nchunks) y = nchunks;
-  return y < 1 ? 1 : y;
+  if (y < 1) y = 1;
+  const int per = (nchunks + y - 1)/y;  // chunks per workgroup
+  return (nchunks + per - 1)/per;
 }
 
 }  // namespace
@@ -1165,7 +1173,7 @@ int cedr_hip_tree_up (const cedr_hip_stage* st, int32_t nfields, const uint8_t* 
   const size_t lds = sizeof(double)*(meta_doubles(st) + static_cast<size_t>(kUpFT)*pitch) +
     sizeof(int32_t)*static_cast<size_t>(nfields + 2 + kWave);  // + op table, + output node ids
   if (lds > 160*1024) return static_cast<int>(hipErrorInvalidValue);
-  const dim3 grid(st->ntiles, chunk_split(st->ntiles, (nfields + kUpFT - 1)/kUpFT));
+  const dim3 grid(st->ntiles, chunk_split(st->ntiles, (nfields + kUpFT - 1)/kUpFT, kSplitUp));
   if (st->micro) {
     if (st->max_nleaf > kWave) return static_cast<int>(hipErrorInvalidValue);
     int e = set_lds_limit(tree_up_micro_kernel<kUpFT>, lds);
@@ -1199,14 +1207,14 @@ int cedr_hip_qlt_down (const cedr_hip_qlt_layout* lay, const cedr_hip_stage* st,
     const size_t ldsm = sizeof(double)*(meta_doubles(st) + 3*mn + static_cast<size_t>(TTm)*pitch);
     int e = set_lds_limit(qlt_down_micro_kernel<TW>, ldsm);
     if (e) return e;
-    const dim3 gridm(st->ntiles, chunk_split(st->ntiles, (lay->nt + TTm - 1)/TTm));
+    const dim3 gridm(st->ntiles, chunk_split(st->ntiles, (lay->nt + TTm - 1)/TTm, kSplitDown));
     hipLaunchKernelGGL(qlt_down_micro_kernel<TW>, gridm, dim3(kBlock), ldsm, stream,
                        *lay, *st, l2r, r2l, pitch);
     return launch_status();
   }
   const size_t lds = sizeof(double)*(meta_doubles(st) + 3*mn + static_cast<size_t>(kDownTT)*pitch);
   if (lds > 160*1024) return static_cast<int>(hipErrorInvalidValue);
-  const dim3 grid(st->ntiles, chunk_split(st->ntiles, (lay->nt + kDownTT - 1)/kDownTT));
+  const dim3 grid(st->ntiles, chunk_split(st->ntiles, (lay->nt + kDownTT - 1)/kDownTT, kSplitUp));
   if (st->max_nleaf <= 128) {
     int e = set_lds_limit(qlt_down_kernel<kDownTT, 2>, lds);
     if (e) return e;
