@@ -1,6 +1,5 @@
 #include "cedr_engine.hpp"
 
-#include <map>
 
 namespace cedr {
 namespace engine {
@@ -40,15 +39,17 @@ TreeEngine::TreeEngine (const mpi::Parallel::Ptr& p, const tree::FlatTree& t,
 {
   // Local cell index of every owned leaf = its NodeSets offset (the reference's
   // numbering, visible to callers through get_owned_glblcells).
-  std::map<Int,Int> gci2lci;
-  for (const Int idx : ns.levels[0].nodes) gci2lci[ns.node_h(idx)->id] = ns.node_h(idx)->offset;
+  util::IdMap gci2lci;
+  gci2lci.reserve(ns.levels[0].nodes.size());
+  for (const Int idx : ns.levels[0].nodes) gci2lci.add(ns.node_h(idx)->id, ns.node_h(idx)->offset);
+  gci2lci.finish();
   std::vector<int32_t> leaf_slot(t.size(), -1);
   const Int me = p->rank();
   for (Int n = 0; n < t.size(); ++n)
     if (t.nkids[n] == 0 && t.rank[n] == me) {
-      const auto it = gci2lci.find(static_cast<Int>(t.cellidx[n]));
-      cedr_throw_if(it == gci2lci.end(), "owned leaf " << t.cellidx[n] << " missing from NodeSets");
-      leaf_slot[n] = it->second;
+      const int lci = gci2lci.find(static_cast<Int>(t.cellidx[n]));
+      cedr_throw_if(lci < 0, "owned leaf " << t.cellidx[n] << " missing from NodeSets");
+      leaf_slot[n] = lci;
     }
   plan_ = plan::build(t, me, p->size(), leaf_slot, opt);
   // Rounded up to 16 doubles (128-byte rows) with at least two spare slots per

@@ -377,6 +377,9 @@ __device__ __forceinline__ double micro_up (const int shape, const int o, const 
 __device__ unsigned long long g_stamps[64];
 # define STAMP(i) do { const unsigned long long _t = __builtin_amdgcn_s_memtime(); \
     __builtin_amdgcn_s_waitcnt(0xC07F); acc[i] += _t - t_prev; t_prev = _t; } while (0)
+#elif defined(CEDR_MARKS)
+// Diagnostic build only: comments in the ISA at the phase boundaries (count instructions between them).
+# define STAMP(i) asm volatile("; MARK " #i ::: "memory")
 #else
 # define STAMP(i)
 #endif

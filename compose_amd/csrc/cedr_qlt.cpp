@@ -95,10 +95,12 @@ void QLTHip::init (const Parallel::Ptr& p, const Int& ncells, const tree::FlatTr
   ns_ = tree::analyze(p->rank(), ncells, tree);
   cedr_throw_if(ns_->levels.empty() || ns_->levels[0].nodes.empty(),
                 "QLT does not support 0 cells on a rank.");
+  gci2lci_.reserve(ns_->levels[0].nodes.size());
   for (const Int idx : ns_->levels[0].nodes) {
     const auto n = ns_->node_h(idx);
-    gci2lci_[n->id] = n->offset;
+    gci2lci_.add(n->id, n->offset);
   }
+  gci2lci_.finish();
   plan::Options popt;
   // Tuning / testing knobs: tile size of the non-micro stages, micro tiles on or off.
   if (const char* e = std::getenv("CEDR_HIP_TILE_LEAVES")) popt.max_tile_leaves = std::atoi(e);
@@ -141,9 +143,9 @@ void QLTHip::get_owned_glblcells (std::vector<Long>& gcis) const {
 }
 
 Int QLTHip::gci2lci (const Int& gci) const {
-  const auto it = gci2lci_.find(gci);
-  cedr_throw_if(it == gci2lci_.end(), "gci " << gci << " not in gci2lci map.");
-  return it->second;
+  const int lci = gci2lci_.find(gci);
+  cedr_throw_if(lci < 0, "gci " << gci << " not in gci2lci map.");
+  return lci;
 }
 
 // ---- tracer declaration: reference cedr_qlt.cpp:276-325 ----

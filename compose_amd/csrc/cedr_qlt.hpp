@@ -4,12 +4,12 @@
 #ifndef COMPOSE_AMD_CEDR_QLT_HPP
 #define COMPOSE_AMD_CEDR_QLT_HPP
 
-#include <map>
 #include <memory>
 #include <vector>
 
 #include "cedr_cdr.hpp"
 #include "cedr_tree.hpp"
+#include "cedr_util.hpp"
 
 typedef struct ihipStream_t* hipStream_t;
 
@@ -106,7 +106,7 @@ private:
   Parallel::Ptr p_;
   std::shared_ptr<const tree::NodeSets> ns_;
   std::unique_ptr<engine::TreeEngine> eng_;
-  std::map<Int,Int> gci2lci_;
+  util::IdMap gci2lci_;
   std::unique_ptr<std::vector<int> > mdb_;  // tracer declarations in progress
   MetaData md_;
   std::unique_ptr<Impl> d_;
