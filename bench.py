@@ -322,6 +322,22 @@ def main():
                         peak=HBM_PEAK_GBS, unit="GB/s", frac=dom["frac"], traffic=dom.get("traffic"),
                         avg_ms=dom["avg_ms"], algorithmic_bytes_per_launch=dom["algorithmic_bytes"])
 
+    # Pack / unpack either side of run() (reported apart from `value`).
+    def timed_sync(fn, reps=5):
+        fn(); torch.cuda.synchronize()
+        s0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - s0) / reps
+    out_buf = torch.empty_like(Qm)
+    t_set = timed_sync(lambda: qlt.set_Qm(Qm, Qm_min, Qm_max, Qm_prev))
+    t_get = timed_sync(lambda: qlt.get_Qm(out_buf))
+    pack = {"qlt_set_Qm_ms": 1e3 * t_set, "qlt_set_Qm_GBs": 64.0 * n * nt / t_set / 1e9,
+            "qlt_get_Qm_ms": 1e3 * t_get, "qlt_get_Qm_GBs": 16.0 * n * nt / t_get / 1e9,
+            "note": "bulk [tracer][cell] arrays <-> field-major QLT buffers; CAAS reads caller arrays in place"}
+    del out_buf
+
     ok = None
     if a.check:
         out = torch.empty_like(Qm)
@@ -362,7 +378,7 @@ def main():
                        "transport": transport},
             "qlt": {"ms_per_run": 1e3 * t_qlt, "updates_per_s": ncells * nt / t_qlt},
             "caas": {"ms_per_run": 1e3 * t_caas, "updates_per_s": ncells * nt / t_caas},
-            "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu,
+            "pack_unpack": pack, "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu,
         }
         if ok is not None:
             line["check_ok"] = ok
