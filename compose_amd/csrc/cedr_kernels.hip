@@ -507,47 +507,74 @@ void tree_up_micro_kernel (const cedr_hip_stage st, const int nfields,
 #endif
 }
 
-// The two node problems of a micro-subtree, in registers. TONLY (a tracer that
-// carries the global q bounds instead of its cells' own) is a compile-time flag,
-// so the common tracer types carry no per-lane selects for that case; callers
-// branch on it wave-uniformly.
+// A micro-subtree by ROLES instead of cell positions: t = (u, v) is its inner
+// pair and p the third cell, so ((a,b),c) has (u,v,p) = (a,b,c) and root kids
+// (t,p); (a,(b,c)) has (u,v,p) = (b,c,a) and root kids (p,t); (a,b) is t alone;
+// a single cell is u alone. Addressing cells by role (offsets oUV / oP from the
+// tile's first cell) keeps every per-lane shape decision out of the data path:
+// no selects on loaded values, and the inner problem is the same code for all
+// shapes.
+struct Roles { int oUV, oP, shape; };
+
+__device__ __forceinline__ Roles get_roles (const Micro& m) {
+  Roles r;
+  r.shape = m.shape;
+  r.oUV = m.start + (m.shape == 3 ? 1 : 0);
+  r.oP = m.shape == 3 ? m.start : (m.shape == 2 ? m.start + 2 : m.start);
+  return r;
+}
+
+// u and v ride in one 16-byte load, p in an 8-byte one; unconditional like
+// load_cells (roles a shape does not have read a neighbouring slot and are ignored).
+__device__ __forceinline__ void load_roles (const double* __restrict__ row, const Roles& r,
+                                            double& u, double& v, double& p) {
+  const Pair uv = *reinterpret_cast<const Pair*>(row + r.oUV);
+  u = uv.x;
+  v = uv.y;
+  p = row[r.oP];
+}
+
+__device__ __forceinline__ void store_roles (double* __restrict__ row, const Roles& r,
+                                             const double u, const double v, const double p) {
+  if (r.shape >= 1) {
+    Pair uv; uv.x = u; uv.y = v;
+    *reinterpret_cast<Pair*>(row + r.oUV) = uv;
+  } else if (r.shape == 0) {
+    row[r.oUV] = u;
+  }
+  if (r.shape >= 2) row[r.oP] = p;
+}
+
+// The node problems of a micro-subtree, in registers: the root's (shapes 2, 3),
+// then the inner pair's (shapes 1, 2, 3; for shape 1 the pair IS the root).
+// cur[role u,v,p][lo, orig, hi]; T and RR are the records of t and of the root.
+// any2 / any3: whether any lane of the wave has shape 2 / 3 (wave-uniform), so a
+// tree that only produces one of them pays for one root problem, not two.
+// TONLY (a tracer that carries the global q bounds instead of its cells' own) is
+// a compile-time flag; callers branch on it wave-uniformly.
 template <bool TONLY>
 __device__ __forceinline__
-void micro_solves (const int shape, const int pt, const double rr, const KidRho ka, const KidRho kb,
-                   const KidRho kc, const KidRho kt, const double (&cur)[3][3], const double (&T)[3],
-                   const double (&RR)[3], const double Xr, const double qlw, const double qhw,
-                   const bool prefer, double& Xa, double& Xb, double& Xc) {
-  double Xt = 0;
+void micro_solves (const int shape, const bool any2, const bool any3, const int pt, const double rr,
+                   const KidRho ku, const KidRho kv, const KidRho kp, const KidRho kt,
+                   const double (&cur)[3][3], const double (&T)[3], const double (&RR)[3],
+                   const double Xr, const double qlw, const double qhw, const bool prefer,
+                   double& Xu, double& Xv, double& Xp) {
 #define CEDR_LO(x) (TONLY ? qlw : (x))
 #define CEDR_HI(x) (TONLY ? qhw : (x))
-  if (shape >= 1) {
-    // root -> (k0, k1): shape 1 (a,b); 2 (t,c); 3 (a,t)
-    const bool s2 = shape == 2, s1 = shape == 1;
-    const KidRho r0 = s2 ? kt : ka;
-    const KidRho r1 = s1 ? kb : (s2 ? kc : kt);
-    const double l0 = s2 ? T[0] : cur[0][0], o0 = s2 ? T[1] : cur[0][1], h0 = s2 ? T[2] : cur[0][2];
-    const double l1 = s1 ? cur[1][0] : (s2 ? cur[2][0] : T[0]);
-    const double o1 = s1 ? cur[1][1] : (s2 ? cur[2][1] : T[1]);
-    const double h1 = s1 ? cur[1][2] : (s2 ? cur[2][2] : T[2]);
-    double x0, x1;
-    solve_node(pt, rr, CEDR_LO(RR[0]), RR[1], CEDR_HI(RR[2]), Xr, r0, CEDR_LO(l0), o0, CEDR_HI(h0),
-               r1, CEDR_LO(l1), o1, CEDR_HI(h1), x0, x1, prefer);
-    if (s2) Xt = x0; else Xa = x0;
-    if (s1) Xb = x1; else if (s2) Xc = x1; else Xt = x1;
-  }
-  if (shape >= 2) {
-    // t -> shape 2 (a,b); 3 (b,c)
-    const bool s2 = shape == 2;
-    const KidRho r0 = s2 ? ka : kb;
-    const KidRho r1 = s2 ? kb : kc;
-    double x0, x1;
+  double Xt = Xr;  // shape 1: the pair is the root
+  if (any2 && shape == 2)
+    solve_node(pt, rr, CEDR_LO(RR[0]), RR[1], CEDR_HI(RR[2]), Xr,
+               kt, CEDR_LO(T[0]), T[1], CEDR_HI(T[2]),
+               kp, CEDR_LO(cur[2][0]), cur[2][1], CEDR_HI(cur[2][2]), Xt, Xp, prefer);
+  if (any3 && shape == 3)
+    solve_node(pt, rr, CEDR_LO(RR[0]), RR[1], CEDR_HI(RR[2]), Xr,
+               kp, CEDR_LO(cur[2][0]), cur[2][1], CEDR_HI(cur[2][2]),
+               kt, CEDR_LO(T[0]), T[1], CEDR_HI(T[2]), Xp, Xt, prefer);
+  Xu = Xr;  // shape 0
+  if (shape >= 1)
     solve_node(pt, kt.rh, CEDR_LO(T[0]), T[1], CEDR_HI(T[2]), Xt,
-               r0, CEDR_LO(s2 ? cur[0][0] : cur[1][0]), s2 ? cur[0][1] : cur[1][1],
-               CEDR_HI(s2 ? cur[0][2] : cur[1][2]),
-               r1, CEDR_LO(s2 ? cur[1][0] : cur[2][0]), s2 ? cur[1][1] : cur[2][1],
-               CEDR_HI(s2 ? cur[1][2] : cur[2][2]), x0, x1, prefer);
-    if (s2) { Xa = x0; Xb = x1; } else { Xb = x0; Xc = x1; }
-  }
+               ku, CEDR_LO(cur[0][0]), cur[0][1], CEDR_HI(cur[0][2]),
+               kv, CEDR_LO(cur[1][0]), cur[1][1], CEDR_HI(cur[1][2]), Xu, Xv, prefer);
 #undef CEDR_LO
 #undef CEDR_HI
 }
@@ -582,7 +609,8 @@ void qlt_down_micro_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st
   const int nt = L.nt;
   const int nchunks = (nt + TT - 1)/TT;
   const Micro m = get_micro(st, tile, lane);
-  const int cell0 = tile.in0 + m.start;
+  const Roles ro = get_roles(m);
+  const bool any2 = __ballot(m.shape == 2) != 0, any3 = __ballot(m.shape == 3) != 0;
 
   // Input records {lo, orig, hi} of this lane's cells for tracer bi (see
   // qlt_down_kernel for which l2r fields they are).
@@ -594,14 +622,13 @@ void qlt_down_micro_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st
       sp = (pt & SHAPEPRESERVE) != 0;
       field = L.bidx_l2r[bi] + (sp ? 0 : ((pt & CONSISTENT) ? 1 : 0));
     }
-    const double* __restrict__ s0 = l2r + static_cast<size_t>(field)*S + cell0;
-    const int sz = bi < nt ? m.size : 0;
+    const double* __restrict__ s0 = l2r + static_cast<size_t>(field)*S + tile.in0;
     if (sp) {
-      load_cells(s0, sz, buf[0][0], buf[1][0], buf[2][0]);
-      load_cells(s0 + S, sz, buf[0][1], buf[1][1], buf[2][1]);
-      load_cells(s0 + 2*S, sz, buf[0][2], buf[1][2], buf[2][2]);
+      load_roles(s0, ro, buf[0][0], buf[1][0], buf[2][0]);
+      load_roles(s0 + S, ro, buf[0][1], buf[1][1], buf[2][1]);
+      load_roles(s0 + 2*S, ro, buf[0][2], buf[1][2], buf[2][2]);
     } else {
-      load_cells(s0, sz, buf[0][1], buf[1][1], buf[2][1]);
+      load_roles(s0, ro, buf[0][1], buf[1][1], buf[2][1]);
       buf[0][0] = buf[1][0] = buf[2][0] = 0.0;
       buf[0][2] = buf[1][2] = buf[2][2] = 0.0;
     }
@@ -612,24 +639,25 @@ void qlt_down_micro_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st
   unsigned long long t_prev = __builtin_amdgcn_s_memtime();
   __builtin_amdgcn_s_waitcnt(0xC07F);
 #endif
-  double cur[TW][3][3];  // [tracer of this wave][cell a,b,c][lo, orig, hi]
+  double cur[TW][3][3];  // [tracer of this wave][role u,v,p][lo, orig, hi]
 #pragma unroll
   for (int s = 0; s < TW; ++s) load(blockIdx.y*TT + wave + kNW*s, cur[s]);
 
-  // Densities of this lane's micro-subtree: cells a, b, c, the inner pair t and
+  // Densities of this lane's micro-subtree: roles u, v, p, the inner pair t and
   // the root, with 1/rhom and 1/(1/rhom) of everything that can be a kid.
   double rr;
-  KidRho ka, kb, kc, kt;
+  KidRho ku, kv, kp, kt;
   {
-    load_cells(l2r + cell0, m.size, ka.rh, kb.rh, kc.rh);
-    if (m.size < 1) ka.rh = 1.0;
-    if (m.size < 2) kb.rh = 1.0;
-    if (m.size < 3) kc.rh = 1.0;
-    kt.rh = (m.shape == 3 ? kb.rh : ka.rh) + (m.shape == 3 ? kc.rh : kb.rh);
-    rr = m.shape <= 0 ? ka.rh : (m.shape == 1 ? kt.rh : (m.shape == 2 ? kt.rh + kc.rh : ka.rh + kt.rh));
-    ka.w = 1.0/ka.rh; ka.q = 1.0/ka.w;
-    kb.w = 1.0/kb.rh; kb.q = 1.0/kb.w;
-    kc.w = 1.0/kc.rh; kc.q = 1.0/kc.w;
+    load_roles(l2r + tile.in0, ro, ku.rh, kv.rh, kp.rh);
+    if (m.shape < 0) ku.rh = 1.0;
+    if (m.shape < 1) kv.rh = 1.0;
+    if (m.shape < 2) kp.rh = 1.0;
+    kt.rh = ku.rh + kv.rh;
+    // (a,b)+c and a+(b,c) are the same sum: fp addition commutes
+    rr = m.shape <= 0 ? ku.rh : (m.shape == 1 ? kt.rh : kt.rh + kp.rh);
+    ku.w = 1.0/ku.rh; ku.q = 1.0/ku.w;
+    kv.w = 1.0/kv.rh; kv.q = 1.0/kv.w;
+    kp.w = 1.0/kp.rh; kp.q = 1.0/kp.w;
     kt.w = 1.0/kt.rh; kt.q = 1.0/kt.w;
     if (wave == 0 && lane < nleaf) rho[lane] = rr;
   }
@@ -664,11 +692,8 @@ void qlt_down_micro_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st
       double* const Rw = recs + (wave + kNW*s)*pitch;
 #pragma unroll
       for (int f = 0; f < 3; ++f) {
-        const double u = m.shape == 3 ? cur[s][1][f] : cur[s][0][f];
-        const double vv = m.shape == 3 ? cur[s][2][f] : cur[s][1][f];
-        const double t = u + vv;
-        const double r = m.shape <= 0 ? cur[s][0][f] :
-          (m.shape == 1 ? t : (m.shape == 2 ? t + cur[s][2][f] : cur[s][0][f] + t));
+        const double t = cur[s][0][f] + cur[s][1][f];
+        const double r = m.shape <= 0 ? cur[s][0][f] : (m.shape == 1 ? t : t + cur[s][2][f]);
         if (lane < nleaf) Rw[4*lane + f] = r;
       }
     }
@@ -762,22 +787,21 @@ void qlt_down_micro_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st
       double T[3], RR[3];  // inner pair t and micro root: {lo, orig, hi} sums, re-formed
 #pragma unroll
       for (int f = 0; f < 3; ++f) {
-        const double u = m.shape == 3 ? cur[s][1][f] : cur[s][0][f];
-        const double vv = m.shape == 3 ? cur[s][2][f] : cur[s][1][f];
-        T[f] = u + vv;
-        RR[f] = m.shape <= 0 ? cur[s][0][f] :
-          (m.shape == 1 ? T[f] : (m.shape == 2 ? T[f] + cur[s][2][f] : cur[s][0][f] + T[f]));
+        T[f] = cur[s][0][f] + cur[s][1][f];
+        RR[f] = m.shape <= 0 ? cur[s][0][f] : (m.shape == 1 ? T[f] : T[f] + cur[s][2][f]);
       }
       const double Xr = recs[(wave + kNW*s)*pitch + 4*lane + 3];
-      double Xa = Xr, Xb = 0, Xc = 0;
+      double Xu = Xr, Xv = 0, Xp = 0;
       if (t_onlyw)
-        micro_solves<true>(m.shape, ptw, rr, ka, kb, kc, kt, cur[s], T, RR, Xr, qlw, qhw, prefer, Xa, Xb, Xc);
+        micro_solves<true>(m.shape, any2, any3, ptw, rr, ku, kv, kp, kt, cur[s], T, RR, Xr, qlw, qhw, prefer,
+                           Xu, Xv, Xp);
       else
-        micro_solves<false>(m.shape, ptw, rr, ka, kb, kc, kt, cur[s], T, RR, Xr, qlw, qhw, prefer, Xa, Xb, Xc);
-      double* __restrict__ dst = r2l + static_cast<size_t>(rbw)*S + cell0;
-      store_cells(dst, m.size, Xa, Xb, Xc);
+        micro_solves<false>(m.shape, any2, any3, ptw, rr, ku, kv, kp, kt, cur[s], T, RR, Xr, qlw, qhw, prefer,
+                            Xu, Xv, Xp);
+      store_roles(r2l + static_cast<size_t>(rbw)*S + tile.in0, ro, Xu, Xv, Xp);
       if (t_onlyw) {
-        double* __restrict__ l0p = l2r + static_cast<size_t>(L.bidx_l2r[biw])*S + cell0;
+        double* __restrict__ dst = r2l + static_cast<size_t>(rbw)*S + tile.in0 + m.start;
+        double* __restrict__ l0p = l2r + static_cast<size_t>(L.bidx_l2r[biw])*S + tile.in0 + m.start;
         for (int k = 0; k < m.size; ++k) {
           dst[S + k] = qlw; dst[2*S + k] = qhw; l0p[k] = qlw; l0p[2*S + k] = qhw;
         }
