@@ -93,3 +93,68 @@ def test_offsets_beyond_int32(gpu, oracle):
     for t in (0, 1, 299, 598, 599):
         ca._chk(L.cedr_memcpy_d2h(row.ctypes.data, out.offset(t * n), row.nbytes))
         assert np.array_equal(row, want), t
+
+
+def test_config_D_sharded_8_ways(gpu, oracle):
+    """BASELINE config D: 6M cells x 128 cst tracers, sharded 8 ways. The 8 ranks run as 8
+    threads on this one GPU (tests/threaded_ranks.py: the real gather / all-gather / scatter /
+    replicated-top path, host-staged transport) and must reproduce the single-rank run of the
+    same problem bit for bit; that run is held to the harness's properties, and three of its
+    tracers to the oracle (tracers are independent, so the oracle runs just those)."""
+    import os
+    import sys
+    import torch
+    import threaded_ranks as T
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    import bench
+    ca = gpu
+    n, nt, P = 6000000, 128, 8
+    dev = torch.device("cuda", 0)
+    rhom, Qm, lo, hi, prev = bench.gen_inputs(torch, n, nt, 0x5EED0000 + 4000, dev)
+    torch.cuda.synchronize()
+
+    q1 = common.make_hip_qlt(ca, ca.Tree.make_1d(n), n, [CST] * nt)
+    b1, b2 = q1.get_buffers_sizes()
+    assert b1 == (2 * n - 1) * (1 + 4 * nt) and b2 == (2 * n - 1) * nt  # reference's sizes (doubles)
+    q1.set_rhom(rhom)
+    q1.set_Qm(Qm, lo, hi, prev)
+    q1.run()
+    out1 = torch.empty_like(Qm)
+    q1.get_Qm(out1)
+    ca.synchronize()
+    del q1
+    assert bool(((out1 >= lo) & (out1 <= hi)).all())
+    rel = (out1.sum(1) - prev.sum(1)).abs() / prev.abs().sum(1)
+    assert float(rel.max()) <= 1e-13
+
+    out8 = torch.zeros_like(Qm)
+
+    def body(rank, comm):
+        q = ca.QLT(comm.parallel(ca, rank), n, ca.Tree.make_1d(n, P, False, False))
+        for _ in range(nt):
+            q.declare_tracer(CST, 0)
+        q.end_tracer_declarations()
+        q.finish_setup()
+        g = torch.from_numpy(q.get_owned_glblcells().astype(np.int64)).to(dev)
+        loc = [x.index_select(x.dim() - 1, g).contiguous() for x in (rhom, Qm, lo, hi, prev)]
+        torch.cuda.synchronize()
+        q.set_rhom(loc[0])
+        q.set_Qm(loc[1], loc[2], loc[3], loc[4])
+        q.run()
+        o = torch.empty_like(loc[1])
+        q.get_Qm(o)
+        ca.synchronize()
+        out8[:, g] = o
+        return int(g.numel())
+    counts = T.run_ranks(P, body, timeout=1200)
+    assert counts == [n // P] * P
+    torch.cuda.synchronize()
+    assert torch.equal(out1, out8)
+
+    sub = [0, 63, 127]
+    vs = R.Values(len(sub), n)
+    vs.rhom[:] = rhom.cpu().numpy()
+    for k, t in enumerate(sub):
+        vs.Qm[k], vs.Qm_min[k], vs.Qm_max[k], vs.Qm_prev[k] = (x[t].cpu().numpy() for x in (Qm, lo, hi, prev))
+    want = common.run_oracle_qlt(oracle, (False, False), n, 1, [CST] * len(sub), vs)
+    assert np.array_equal(out1[sub].cpu().numpy(), want)

@@ -1,0 +1,118 @@
+"""P ranks of the product as P threads of ONE process on ONE GPU (test infrastructure).
+
+The container and the GPU box have one GPU, and RCCL refuses two ranks on one device,
+so this is how the multi-rank data path -- gather of subtree roots, all-gather,
+scatter, replicated top sweep, CAAS all-reduce -- runs on real hardware with P > 3:
+every rank is a thread with its own cedr::mpi::Parallel (callbacks transport); the
+collectives meet at a barrier and exchange host copies. ctypes releases the GIL
+around library calls, so ranks really interleave on the device.
+"""
+import threading
+
+import numpy as np
+
+
+class ThreadComm:
+    def __init__(self, nranks, timeout=600):
+        self.P = nranks
+        self.bar = threading.Barrier(nranks, timeout=timeout)
+        self.slots = [None] * nranks
+
+    def allgather(self, rank, x):
+        self.slots[rank] = np.array(x, dtype=np.float64)
+        self.bar.wait()
+        out = np.concatenate(self.slots)
+        self.bar.wait()
+        return out
+
+    def allreduce(self, rank, x):
+        self.slots[rank] = np.array(x, dtype=np.float64)
+        self.bar.wait()
+        out = self.slots[0].copy()
+        for q in range(1, self.P):  # fixed order: identical bits on every rank
+            out += self.slots[q]
+        self.bar.wait()
+        return out
+
+    def parallel(self, ca, rank):
+        return ca.Parallel.host_staged(rank, self.P, lambda x: self.allgather(rank, x),
+                                       lambda x: self.allreduce(rank, x))
+
+
+def run_ranks(nranks, body, timeout=600):
+    """body(rank, comm) on nranks threads; re-raises the first failure."""
+    comm = ThreadComm(nranks, timeout)
+    errs = [None] * nranks
+    res = [None] * nranks
+
+    def wrap(r):
+        try:
+            res[r] = body(r, comm)
+        except BaseException as e:  # noqa: BLE001 -- reported to the caller below
+            errs[r] = e
+            comm.bar.abort()
+    ts = [threading.Thread(target=wrap, args=(r,)) for r in range(nranks)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    real = [e for e in errs if e is not None and not isinstance(e, threading.BrokenBarrierError)]
+    if real:
+        raise real[0]
+    if any(errs):
+        raise [e for e in errs if e][0]
+    return res
+
+
+def run_qlt(ca, nranks, ncells, types, v, prefer=False, pseudorandom=False, imbalanced=False, nrepeat=1):
+    """Global arrays in, global result out; every rank owns what Tree.make_1d gives it."""
+    out = np.zeros_like(v.Qm)
+
+    def body(rank, comm):
+        tree = ca.Tree.make_1d(ncells, nranks, pseudorandom, imbalanced)
+        q = ca.QLT(comm.parallel(ca, rank), ncells, tree, prefer)
+        for t in types:
+            q.declare_tracer(t, 0)
+        q.end_tracer_declarations()
+        q.finish_setup()
+        g = q.get_owned_glblcells()
+        d = [ca.DeviceArray.from_numpy(a) for a in
+             (v.rhom[g], v.Qm[:, g], v.Qm_min[:, g], v.Qm_max[:, g], v.Qm_prev[:, g])]
+        q.set_rhom(d[0])
+        for _ in range(nrepeat):
+            q.set_Qm(d[1], d[2], d[3], d[4])
+            q.run()
+        od = ca.DeviceArray(len(types) * len(g))
+        q.get_Qm(od)
+        ca.synchronize()
+        out[:, g] = od.numpy((len(types), len(g)))
+        return len(g)
+    counts = run_ranks(nranks, body)
+    assert sum(counts) == ncells
+    return out
+
+
+def run_caas(ca, nranks, ncells, types, v):
+    """Contiguous split of the global arrays; returns the global result."""
+    out = np.zeros_like(v.Qm)
+    bounds = [ncells * r // nranks for r in range(nranks + 1)]
+
+    def body(rank, comm):
+        sl = slice(bounds[rank], bounds[rank + 1])
+        n = bounds[rank + 1] - bounds[rank]
+        c = ca.CAAS(comm.parallel(ca, rank), n)
+        for t in types:
+            c.declare_tracer(t, 0)
+        c.end_tracer_declarations()
+        c.finish_setup()
+        d = [ca.DeviceArray.from_numpy(a) for a in
+             (v.rhom[sl], v.Qm[:, sl], v.Qm_min[:, sl], v.Qm_max[:, sl], v.Qm_prev[:, sl])]
+        c.set_rhom(d[0])
+        c.set_Qm(d[1], d[2], d[3], d[4])
+        c.run()
+        od = ca.DeviceArray(len(types) * n)
+        c.get_Qm(od)
+        ca.synchronize()
+        out[:, sl] = od.numpy((len(types), n))
+    run_ranks(nranks, body)
+    return out, [bounds[r + 1] - bounds[r] for r in range(nranks)]
