@@ -588,6 +588,7 @@ void micro_solves (const int shape, const bool any2, const bool any3, const int 
 #ifndef CEDR_MICRO_TW
 # define CEDR_MICRO_TW 2  // tracers per wave and chunk in the micro down sweep
 #endif
+constexpr int kCellRho = 12;  // LDS doubles per micro-subtree: {rh, w, q} of u, v, p, t
 template <int TW>
 __global__ __launch_bounds__(kBlock, CEDR_MICRO_WAVES)
 void qlt_down_micro_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st,
@@ -602,7 +603,8 @@ void qlt_down_micro_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st
   double* const rho = lds + (st.max_nint + 1);
   double* const rw = rho + MN;
   double* const rq = rw + MN;
-  double* const recs = rq + MN;
+  double* const cellrho = rq + MN;            // [kCellRho][kWave]
+  double* const recs = cellrho + kCellRho*kWave;
   const int nleaf = tile.nleaf;
   const int64_t S = L.stride;
   const bool prefer = L.prefer_mass_con != 0;
@@ -645,21 +647,27 @@ void qlt_down_micro_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st
 
   // Densities of this lane's micro-subtree: roles u, v, p, the inner pair t and
   // the root, with 1/rhom and 1/(1/rhom) of everything that can be a kid.
-  double rr;
-  KidRho ku, kv, kp, kt;
-  {
-    load_roles(l2r + tile.in0, ro, ku.rh, kv.rh, kp.rh);
-    if (m.shape < 0) ku.rh = 1.0;
-    if (m.shape < 1) kv.rh = 1.0;
-    if (m.shape < 2) kp.rh = 1.0;
-    kt.rh = ku.rh + kv.rh;
+  // They are the same for every wave and tracer: wave 0 derives them once per tile
+  // and parks them in LDS, so they hold registers only while a micro-subtree is
+  // being solved: 156 VGPRs and no spills instead of 168 plus spills (3 waves/SIMD
+  // either way), and the eight divisions per micro-subtree happen once, not per wave.
+  if (wave == 0) {
+    double rh[4];
+    load_roles(l2r + tile.in0, ro, rh[0], rh[1], rh[2]);
+    if (m.shape < 0) rh[0] = 1.0;
+    if (m.shape < 1) rh[1] = 1.0;
+    if (m.shape < 2) rh[2] = 1.0;
+    rh[3] = rh[0] + rh[1];
     // (a,b)+c and a+(b,c) are the same sum: fp addition commutes
-    rr = m.shape <= 0 ? ku.rh : (m.shape == 1 ? kt.rh : kt.rh + kp.rh);
-    ku.w = 1.0/ku.rh; ku.q = 1.0/ku.w;
-    kv.w = 1.0/kv.rh; kv.q = 1.0/kv.w;
-    kp.w = 1.0/kp.rh; kp.q = 1.0/kp.w;
-    kt.w = 1.0/kt.rh; kt.q = 1.0/kt.w;
-    if (wave == 0 && lane < nleaf) rho[lane] = rr;
+    const double rr = m.shape <= 0 ? rh[0] : (m.shape == 1 ? rh[3] : rh[3] + rh[2]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const double w = 1.0/rh[r];
+      cellrho[(3*r    )*kWave + lane] = rh[r];
+      cellrho[(3*r + 1)*kWave + lane] = w;
+      cellrho[(3*r + 2)*kWave + lane] = 1.0/w;
+    }
+    if (lane < nleaf) rho[lane] = rr;
   }
   stage_tile_meta(st, tile, kidsL, lvlL);
   __syncthreads();
@@ -773,6 +781,12 @@ void qlt_down_micro_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st
     STAMP(4);  // phase B
     // ---- this wave's tracers again: node problems of the micro-subtree in
     // registers, then the cells' masses to HBM.
+    KidRho ku, kv, kp, kt;
+    ku.rh = cellrho[0*kWave + lane]; ku.w = cellrho[1*kWave + lane]; ku.q = cellrho[2*kWave + lane];
+    kv.rh = cellrho[3*kWave + lane]; kv.w = cellrho[4*kWave + lane]; kv.q = cellrho[5*kWave + lane];
+    kp.rh = cellrho[6*kWave + lane]; kp.w = cellrho[7*kWave + lane]; kp.q = cellrho[8*kWave + lane];
+    kt.rh = cellrho[9*kWave + lane]; kt.w = cellrho[10*kWave + lane]; kt.q = cellrho[11*kWave + lane];
+    const double rr = rho[lane < nleaf ? lane : 0];
 #pragma unroll
     for (int s = 0; s < TW; ++s) {
       const int biw = c*TT + wave + kNW*s;
@@ -1231,7 +1245,9 @@ int cedr_hip_qlt_down (const cedr_hip_qlt_layout* lay, const cedr_hip_stage* st,
   if (st->micro) {
     if (st->max_nleaf > kWave) return static_cast<int>(hipErrorInvalidValue);
     constexpr int TW = CEDR_MICRO_TW, TTm = kNW*TW;
-    const size_t ldsm = sizeof(double)*(meta_doubles(st) + 3*mn + static_cast<size_t>(TTm)*pitch);
+    const size_t ldsm = sizeof(double)*(meta_doubles(st) + 3*mn + kCellRho*kWave +
+                                        static_cast<size_t>(TTm)*pitch);
+    if (ldsm > 160*1024) return static_cast<int>(hipErrorInvalidValue);
     int e = set_lds_limit(qlt_down_micro_kernel<TW>, ldsm);
     if (e) return e;
     const dim3 gridm(st->ntiles, chunk_split(st->ntiles, (lay->nt + TTm - 1)/TTm, kSplitDown));
