@@ -395,6 +395,12 @@ __device__ __forceinline__ void asm_load_cells (d2v& ab, double& c, const double
   asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx2 %1, %2, off offset:16"
                : "=&v"(ab), "=&v"(c) : "v"(p) : "memory");
 }
+#define CEDR_WAIT_VM0_2(A, C) \
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(A[0]), "+v"(A[1]), "+v"(C[0]), "+v"(C[1]) :: "memory")
+#define CEDR_WAIT_VM0_4(A, C) \
+  asm volatile("s_waitcnt vmcnt(0)" \
+               : "+v"(A[0]), "+v"(A[1]), "+v"(A[2]), "+v"(A[3]), "+v"(C[0]), "+v"(C[1]), "+v"(C[2]), "+v"(C[3]) \
+               :: "memory")
 #define CEDR_WAIT_VM0_8(A, C) \
   asm volatile("s_waitcnt vmcnt(0)" \
                : "+v"(A[0]), "+v"(A[1]), "+v"(A[2]), "+v"(A[3]), "+v"(A[4]), "+v"(A[5]), "+v"(A[6]), \
@@ -416,7 +422,8 @@ __global__ __launch_bounds__(kBlock)
 void tree_up_micro_kernel (const cedr_hip_stage st, const int nfields,
                            const uint8_t* __restrict__ op, const int64_t stride,
                            double* __restrict__ data, const int zero_init, const int pitch) {
-  static_assert(FT == 8*kNW, "the prefetch wait macro is written for 8 rows per wave");
+  static_assert(FT == 8*kNW || FT == 4*kNW || FT == 2*kNW,
+                "the prefetch wait macros are written for 2, 4 or 8 rows per wave");
   extern __shared__ double lds[];
   const cedr_hip_tile tile = st.tiles[blockIdx.x];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & (kWave - 1);
@@ -459,7 +466,9 @@ void tree_up_micro_kernel (const cedr_hip_stage st, const int nfields,
   stage_tile_meta(st, tile, kidsL, lvlL);
   const int ff = threadIdx.x & (FT - 1);
   double* const vf = v + ff*pitch;
-  CEDR_WAIT_VM0_8(cab, ccc);
+  if constexpr (FT == 8*kNW) { CEDR_WAIT_VM0_8(cab, ccc); }
+  else if constexpr (FT == 4*kNW) { CEDR_WAIT_VM0_4(cab, ccc); }
+  else { CEDR_WAIT_VM0_2(cab, ccc); }
   __syncthreads();  // opL, outL and the tile metadata staged
   STAMP(0);  // setup + first chunk's loads
 
@@ -496,7 +505,9 @@ void tree_up_micro_kernel (const cedr_hip_stage st, const int nfields,
         data[static_cast<size_t>(f)*stride + tile.out + k] = vf[outL[k]];
     __syncthreads();
     STAMP(4);  // outputs + barrier
-    CEDR_WAIT_VM0_8(nab, ncc);
+    if constexpr (FT == 8*kNW) { CEDR_WAIT_VM0_8(nab, ncc); }
+    else if constexpr (FT == 4*kNW) { CEDR_WAIT_VM0_4(nab, ncc); }
+    else { CEDR_WAIT_VM0_2(nab, ncc); }
     STAMP(5);  // wait for the prefetched chunk
 #pragma unroll
     for (int r = 0; r < NR; ++r) { cab[r] = nab[r]; ccc[r] = ncc[r]; }
@@ -1179,7 +1190,12 @@ int set_lds_limit (K kernel, size_t bytes) {
                                               static_cast<int>(bytes)));
 }
 
-constexpr int kUpFT = 32;    // fields per chunk, leaves->root
+// Fields per chunk, leaves->root. 16 (4 rows in flight per wave, 74 VGPRs, 6 waves/SIMD) beat 32
+// (125 VGPRs, 4 waves/SIMD) and 8 on hardware: 0.426 vs 0.441 / 0.428 ms at 1.5M cells x 161 fields.
+#ifndef CEDR_UP_FT
+# define CEDR_UP_FT 16
+#endif
+constexpr int kUpFT = CEDR_UP_FT;
 constexpr int kDownTT = 8;   // tracers per chunk, root->leaves
 
 // kid pairs (4 B each) + level offsets (4 B each), rounded up to doubles
