@@ -1,0 +1,139 @@
+// Host-side check of the tile plans the kernels consume, meant to be built with
+// -fsanitize=address,undefined (CPU only): for a sweep of trees, ownerships and
+// planner options it builds NodeSets + plan exactly as TreeEngine does and verifies
+// every precondition the kernel launchers and kernels rely on (index ranges, LDS
+// bounds, micro-subtree shapes, padding reads). A violated precondition on the GPU
+// would be an out-of-bounds access; here it is a message and a non-zero exit.
+#include <cstdio>
+#include <cstdlib>
+#include <set>
+#include <vector>
+
+#include "cedr_plan.hpp"
+#include "cedr_tree.hpp"
+#include "cedr_util.hpp"
+
+using namespace cedr;
+
+static int g_fail = 0;
+#define REQUIRE(c) do { if ( ! (c)) { std::printf("FAIL %s:%d: %s [%s]\n", __FILE__, __LINE__, #c, ctx); ++g_fail; \
+                                     if (g_fail > 20) std::exit(1); } } while (0)
+
+static void check_stage (const plan::Stage& st, const plan::Plan& pl, const int64_t stride, const bool first,
+                         const char* ctx) {
+  REQUIRE(st.max_nleaf <= 256);
+  const bool micro = ! st.micro.empty();
+  if (micro) REQUIRE(st.max_nleaf <= 64);
+  std::set<int> out_slots;
+  for (const auto& t : st.tiles) {
+    REQUIRE(t.nleaf >= 1 && t.nleaf <= st.max_nleaf);
+    REQUIRE(t.nint >= 0 && t.nint <= st.max_nint);
+    REQUIRE(t.nleaf + t.nint <= st.max_nodes);
+    REQUIRE(t.nleaf + t.nint <= 0xffff);
+    REQUIRE(t.nlvl >= 0 && t.lvl_off + t.nlvl < (int) st.lvlptr.size());
+    REQUIRE(2*((size_t) t.kids_off + t.nint) <= st.kids.size());
+    REQUIRE(t.nout >= 1 && (size_t) t.outs_off + t.nout <= st.outs.size());
+    REQUIRE(t.out >= 0 && t.out + t.nout <= pl.nslots);
+    // levels: contiguous prefix over the tile's internal nodes, kids before parents
+    int prev = 0;
+    for (int l = 0; l <= t.nlvl; ++l) {
+      const int v = st.lvlptr[t.lvl_off + l];
+      REQUIRE(v >= prev && v <= t.nint);
+      prev = v;
+    }
+    REQUIRE(st.lvlptr[t.lvl_off] == 0 && st.lvlptr[t.lvl_off + t.nlvl] == t.nint);
+    for (int l = 0; l < t.nlvl; ++l)
+      for (int j = st.lvlptr[t.lvl_off + l]; j < st.lvlptr[t.lvl_off + l + 1]; ++j) {
+        const int k0 = st.kids[2*((size_t) t.kids_off + j)], k1 = st.kids[2*((size_t) t.kids_off + j) + 1];
+        // a kid is an input or an internal node of a LOWER level
+        REQUIRE(k0 < t.nleaf + st.lvlptr[t.lvl_off + l] && k1 < t.nleaf + st.lvlptr[t.lvl_off + l]);
+        REQUIRE(k0 != k1);
+      }
+    for (int k = 0; k < t.nout; ++k) {
+      REQUIRE(st.outs[t.outs_off + k] < t.nleaf + t.nint);
+      REQUIRE(out_slots.insert(t.out + k).second);  // nobody else writes this slot
+    }
+    if (micro) {
+      REQUIRE(t.nout <= 64);
+      REQUIRE((size_t) t.micro_off + t.nleaf <= st.micro.size());
+      int next = 0;
+      for (int i = 0; i < t.nleaf; ++i) {
+        const int d = st.micro[t.micro_off + i], start = d & 0xff, shape = d >> 8;
+        REQUIRE(shape >= 0 && shape <= 3);
+        const int size = shape == 0 ? 1 : (shape == 1 ? 2 : 3);
+        REQUIRE(start == next);  // micro-subtrees tile the input range in order
+        next = start + size;
+      }
+      REQUIRE(next <= 192);
+      REQUIRE(t.in0 >= 0 && t.in0 + next <= pl.nslots);
+      if (first) REQUIRE(t.in0 + next <= pl.nlcl);  // first-stage inputs are cells
+      // unmasked 16 + 8 byte reads may touch two slots past the tile: inside the row
+      REQUIRE((int64_t) t.in0 + next + 2 <= stride);
+    } else {
+      REQUIRE(t.in0 >= 0 && t.in0 + t.nleaf <= pl.nslots);
+    }
+  }
+}
+
+static void check (const tree::FlatTree& t, const int ncells, const int nranks, const plan::Options& opt,
+                   const char* ctx) {
+  for (int me = 0; me < nranks; ++me) {
+    const auto ns = tree::analyze(me, ncells, t);
+    REQUIRE(tree::check_comm(*ns) == 0 || nranks > 1);
+    util::IdMap g2l;
+    for (const Int idx : ns->levels[0].nodes) g2l.add(ns->node_h(idx)->id, ns->node_h(idx)->offset);
+    g2l.finish();
+    std::vector<int32_t> leaf_slot(t.size(), -1);
+    int nown = 0;
+    for (Int n = 0; n < t.size(); ++n)
+      if (t.nkids[n] == 0 && t.rank[n] == me) { leaf_slot[n] = g2l.find((Int) t.cellidx[n]); REQUIRE(leaf_slot[n] >= 0); ++nown; }
+    plan::Plan pl;
+    try { pl = plan::build(t, me, nranks, leaf_slot, opt); }
+    catch (const std::logic_error&) { continue; }  // orders the planner rejects by design
+    REQUIRE(pl.nlcl == nown);
+    const int64_t stride = ((int64_t) pl.nslots + 2 + 15)/16*16;
+    for (size_t i = 0; i < pl.local.size(); ++i) check_stage(pl.local[i], pl, stride, i == 0, ctx);
+    for (size_t i = 0; i < pl.top.size(); ++i) check_stage(pl.top[i], pl, stride, false, ctx);
+    REQUIRE(pl.root_slot >= 0 && pl.root_slot < pl.nslots);
+    if (nranks > 1) {
+      REQUIRE((int) pl.gather_slots.size() == nranks*pl.nb_max);
+      REQUIRE(pl.my_root_slots.size() == pl.my_top_slots.size());
+      REQUIRE((int) pl.my_root_slots.size() <= pl.nb_max);
+      for (const int s : pl.gather_slots) REQUIRE(s >= -1 && s < pl.nslots);
+      for (const int s : pl.my_root_slots) REQUIRE(s >= 0 && s < pl.nslots);
+      for (const int s : pl.my_top_slots) REQUIRE(s >= 0 && s < pl.nslots);
+    }
+  }
+}
+
+int main () {
+  typedef tree::oned::Mesh Mesh;
+  char ctx[160];
+  long ncase = 0;
+  const int sizes[] = {1, 2, 3, 4, 5, 7, 8, 21, 63, 64, 65, 111, 127, 128, 129, 191, 192, 193, 255, 256, 257, 777,
+                       1000, 1024, 4097};
+  const int ranks[] = {1, 2, 3, 8};
+  for (const int nc : sizes)
+    for (const int P : ranks) {
+      if (P > nc || (nc > 1024 && P != 1 && P != 8)) continue;
+      for (int pr = 0; pr < 2; ++pr)
+        for (int imb = 0; imb < 2; ++imb) {
+          const Mesh m(nc, P, pr ? Mesh::ParallelDecomp::pseudorandom : Mesh::ParallelDecomp::contiguous);
+          const tree::FlatTree t = tree::oned::make_flat_tree(m, imb != 0);
+          for (const int tile : {2, 3, 16, 128, 256})
+            for (const int micro : {0, 1})
+              for (const int cut : {0, 1, 3, 5}) {
+                if ( ! micro && cut != 3) continue;
+                plan::Options o;
+                o.max_tile_leaves = tile; o.micro = micro != 0; o.micro_cut = cut;
+                std::snprintf(ctx, sizeof(ctx), "nc %d P %d pseudorandom %d imbalanced %d tile %d micro %d cut %d",
+                              nc, P, pr, imb, tile, micro, cut);
+                check(t, nc, P, o, ctx);
+                ++ncase;
+              }
+        }
+    }
+  std::printf("%ld plans checked, %d failures\n", ncase, g_fail);
+  std::printf(g_fail ? "FAIL\n" : "PASS\n");
+  return g_fail ? 1 : 0;
+}

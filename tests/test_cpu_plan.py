@@ -144,3 +144,16 @@ def test_gloo_two_ranks():
                          capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
     assert "GLOO_OK" in res.stdout
+
+
+def test_plan_invariants_under_sanitizers():
+    """tests/cpp/plan_check.cpp: analyze + plan for ~7000 (tree, ownership, option) cases,
+    built with -fsanitize=address,undefined, checking every index range the kernels rely on."""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cpp")
+    subprocess.check_call(["make", "-s", "-C", d, "plan_check_asan"])
+    res = subprocess.run([os.path.join(d, "plan_check_asan")], capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0 and "PASS" in res.stdout, res.stdout[-2000:] + res.stderr[-3000:]
