@@ -16,19 +16,40 @@ struct Builder {
   std::vector<int32_t> cnt;    // scratch: # current inputs below a node
   std::vector<int32_t> lid;    // scratch: local id inside the tile being built
   std::vector<int32_t> llvl;   // scratch: local level inside the tile being built
-  std::vector<int32_t> nleaves; // # real leaves below a node (filled by the caller)
+  std::vector<int32_t> nin;    // scratch: # current inputs (nodes holding a slot) below a node
   std::vector<int32_t> first_in; // scratch: local id of a node's first input
   std::vector<char> has_parent;  // scratch: node has a kept parent in the tile
   bool micro_mode = false;     // inputs are micro-subtrees (<= 3 leaves) instead of slots
+  bool cut_stage = false;      // the stage being built cuts its tiles (first stage only: later
+                               // stages are small, and every cut adds a stage = a launch)
   int32_t next_slot;
 
   bool is_input (const int32_t n) const {
-    return micro_mode ? nleaves[n] <= 3 : slot[n] >= 0;
+    return micro_mode ? nin[n] <= 3 : slot[n] >= 0;
   }
 
   Builder (const tree::FlatTree& t_, const Options& o)
     : t(t_), opt(o), slot(t_.size(), -1), cnt(t_.size(), 0), lid(t_.size(), -1),
-      llvl(t_.size(), 0), first_in(t_.size(), 0), has_parent(t_.size(), 0), next_slot(0) {}
+      llvl(t_.size(), 0), nin(t_.size(), 0), first_in(t_.size(), 0), has_parent(t_.size(), 0),
+      next_slot(0) {}
+
+  // nin[n] for every node reachable from r without passing through a slot holder.
+  void count_slots (const int32_t r) {
+    std::vector<std::pair<int32_t,int32_t> > st;
+    st.push_back(std::make_pair(r, 0));
+    while ( ! st.empty()) {
+      auto& top = st.back();
+      const int32_t n = top.first;
+      if (slot[n] >= 0) { nin[n] = 1; st.pop_back(); continue; }
+      if (top.second < 2) {
+        const int32_t k = t.kid(n, top.second++);
+        st.push_back(std::make_pair(k, 0));
+      } else {
+        nin[n] = nin[t.kid0[n]] + nin[t.kid1[n]];
+        st.pop_back();
+      }
+    }
+  }
 
   // cnt[n] for every node reachable from r without passing through an input.
   void count_inputs (const int32_t r) {
@@ -67,15 +88,16 @@ struct Builder {
         const int32_t n = top.first;
         if (is_input(n)) {
           if (micro_mode) {
-            // Leaves of the micro-subtree in DFS order, and its shape.
+            // Inputs (slot holders: cells in the first stage, outputs of the
+            // previous stage later) of the micro-subtree in DFS order, and its shape.
             int32_t lv[3], nl = 0;
             int32_t shape = 0;
-            if (t.nkids[n] == 0) lv[nl++] = n;
+            if (slot[n] >= 0) lv[nl++] = n;
             else {
               const int32_t a = t.kid0[n], b = t.kid1[n];
-              if (t.nkids[a] == 0) lv[nl++] = a; else { lv[nl++] = t.kid0[a]; lv[nl++] = t.kid1[a]; }
-              if (t.nkids[b] == 0) lv[nl++] = b; else { lv[nl++] = t.kid0[b]; lv[nl++] = t.kid1[b]; }
-              shape = nl == 2 ? 1 : (t.nkids[a] ? 2 : 3);
+              if (slot[a] >= 0) lv[nl++] = a; else { lv[nl++] = t.kid0[a]; lv[nl++] = t.kid1[a]; }
+              if (slot[b] >= 0) lv[nl++] = b; else { lv[nl++] = t.kid0[b]; lv[nl++] = t.kid1[b]; }
+              shape = nl == 2 ? 1 : (slot[a] < 0 ? 2 : 3);
             }
             for (int32_t i = 0; i < nl; ++i) {
               cedr_throw_if(slot[lv[i]] < 0, "micro-subtree leaf without a slot");
@@ -110,7 +132,7 @@ struct Builder {
       }
     }
     // Cut tiles keep only the internal nodes of local level <= cut.
-    const int32_t cut = (micro_mode && opt.micro_cut > 0) ? opt.micro_cut : 0;
+    const int32_t cut = (micro_mode && cut_stage && opt.micro_cut > 0) ? opt.micro_cut : 0;
     std::vector<int32_t> dropped;
     if (cut > 0) {
       std::vector<int32_t> keep;
@@ -173,15 +195,18 @@ struct Builder {
   std::vector<std::pair<int32_t,int32_t> > pending;  // (tile root, out slot) of the stage
 
   // Reduce every root in 'roots' to a single input slot, appending stages.
+  // micro: 0 = no stage uses micro tiles, 1 = the first stage does, 2 = all do.
   void tile_forest (const std::vector<int32_t>& roots, std::vector<Stage>& stages,
-                    const bool micro_first) {
+                    const int micro, const bool cut_first) {
     bool first = true;
     for (;;) {
-      micro_mode = micro_first && first;
+      micro_mode = micro == 2 || (micro == 1 && first);
+      cut_stage = first && cut_first;
       first = false;
       std::vector<int32_t> active;
       for (const int32_t r : roots) if (slot[r] < 0) active.push_back(r);
       if (active.empty()) break;
+      if (micro_mode) for (const int32_t r : active) count_slots(r);
       for (const int32_t r : active) count_inputs(r);
       Stage st;
       pending.clear();
@@ -245,9 +270,6 @@ Plan build (const tree::FlatTree& t, int32_t my_rank, int32_t nranks,
   }
 
   Builder b(t, opt);
-  b.nleaves.assign(nn, 1);
-  for (const Int n : tree::post_order(t))
-    if (t.nkids[n]) b.nleaves[n] = b.nleaves[t.kid0[n]] + b.nleaves[t.kid1[n]];
   for (int32_t n = 0; n < nn; ++n)
     if (t.nkids[n] == 0 && t.rank[n] == my_rank) {
       cedr_throw_if(leaf_slot[n] < 0, "owned leaf without a local index");
@@ -258,7 +280,7 @@ Plan build (const tree::FlatTree& t, int32_t my_rank, int32_t nranks,
 
   std::vector<int32_t> my_roots;
   for (const int32_t r : broots) if (own[r] == my_rank) my_roots.push_back(r);
-  b.tile_forest(my_roots, p.local, opt.micro);
+  b.tile_forest(my_roots, p.local, opt.micro ? (opt.micro_all ? 2 : 1) : 0, true);
   for (const int32_t r : my_roots) p.my_root_slots.push_back(b.slot[r]);
 
   if (broots.size() > 1) {
@@ -273,7 +295,7 @@ Plan build (const tree::FlatTree& t, int32_t my_rank, int32_t nranks,
       p.gather_slots[static_cast<size_t>(own[r])*p.nb_max + per_rank[own[r]]++] = ts;
       if (own[r] == my_rank) p.my_top_slots.push_back(ts);
     }
-    b.tile_forest(std::vector<int32_t>(1, 0), p.top, false);
+    b.tile_forest(std::vector<int32_t>(1, 0), p.top, (opt.micro && opt.micro_all) ? 2 : 0, false);
   }
   p.root_slot = b.slot[0];
   p.nslots = b.next_slot;

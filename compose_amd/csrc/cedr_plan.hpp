@@ -29,9 +29,9 @@ namespace plan {
 // internal nodes nleaf..nleaf+nint-1 ordered by local level (kids before
 // parents); the tile root is the last node (or input 0 if nint == 0).
 //
-// MICRO tiles (first stage over real cells only): the inputs of the tile's LDS
-// tree are not single slots but "micro-subtrees" of at most 3 consecutive
-// leaves, one per lane, combined/solved in registers. Then nleaf counts the
+// MICRO tiles: the inputs of the tile's LDS tree are not single slots but
+// "micro-subtrees" of at most 3 consecutive inputs (cells in the first stage,
+// outputs of the previous stage later), one per lane, combined/solved in registers. Then nleaf counts the
 // micro-subtrees (<= 64), micro_off points at their descriptors in
 // Stage::micro, and in0 is the slot of the first leaf of the first micro-subtree.
 struct Tile {
@@ -88,6 +88,7 @@ struct Plan {
 struct Options {
   int32_t max_tile_leaves = 128;  // inputs per tile (bounded by the kernels' LDS use)
   bool micro = true;              // first local stage uses micro tiles (64 x <= 3 leaves)
+  bool micro_all = true;          // ... and so does every later stage, over the previous one's outputs
   int32_t micro_cut = 3;          // local levels kept per micro tile (0 = keep all)
 };
 

@@ -104,7 +104,10 @@ void QLTHip::init (const Parallel::Ptr& p, const Int& ncells, const tree::FlatTr
   plan::Options popt;
   // Tuning / testing knobs: tile size of the non-micro stages, micro tiles on or off.
   if (const char* e = std::getenv("CEDR_HIP_TILE_LEAVES")) popt.max_tile_leaves = std::atoi(e);
-  if (const char* e = std::getenv("CEDR_HIP_MICRO")) popt.micro = std::atoi(e) != 0;
+  if (const char* e = std::getenv("CEDR_HIP_MICRO")) {  // 0 = off, 1 = first stage only, 2 = all stages
+    popt.micro = std::atoi(e) != 0;
+    popt.micro_all = std::atoi(e) >= 2;
+  }
   if (const char* e = std::getenv("CEDR_HIP_MICRO_CUT")) popt.micro_cut = std::atoi(e);
   eng_.reset(new engine::TreeEngine(p, tree, *ns_, popt));
   mdb_.reset(new std::vector<int>());

@@ -99,28 +99,33 @@ def test_plan_invariants(ca, tile):
 
 @pytest.mark.parametrize("imbalanced", [False, True])
 def test_micro_plan_invariants(ca, imbalanced):
-    """First stage with micro tiles: <= 64 micro-subtrees of <= 3 consecutive cells per
-    tile, every cell in exactly one of them."""
+    """Every stage uses micro tiles: <= 64 micro-subtrees of <= 3 consecutive inputs per
+    tile; the first stage's inputs are the cells, a later stage's inputs are exactly the
+    previous stage's output slots; every input is in exactly one micro-subtree."""
     nc = 5000
     pl = ca.Tree.make_1d(nc, 1, False, imbalanced).plan(nc, 0, 1, 0)
-    st = pl["local"][0]
-    assert len(st["micro"]) > 0
-    covered = np.zeros(nc, np.int32)
-    for t in st["tiles"]:
-        in0, nleaf, out, nint, koff, loff, nlvl, moff, nout, ooff = [int(x) for x in t]
-        assert 1 <= nleaf <= 64 and nint == nleaf - nout and nlvl <= 3  # cut after 3 levels
-        outs = st["outs"][ooff:ooff + nout]
-        assert len(set(outs)) == nout and (outs < nleaf + nint).all()
-        prev_end = 0
-        for d in st["micro"][moff:moff + nleaf]:
-            start, shape = int(d & 0xff), int(d >> 8)
-            size = 1 if shape == 0 else 2 if shape == 1 else 3
-            assert start == prev_end and 0 <= shape <= 3
-            covered[in0 + start:in0 + start + size] += 1
-            prev_end = start + size
-    assert (covered == 1).all()
-    for later in pl["local"][1:]:
-        assert len(later["micro"]) == 0
+    want = set(range(nc))  # slots the stage must consume
+    assert len(pl["local"]) >= 2
+    for si, st in enumerate(pl["local"]):
+        assert len(st["micro"]) > 0
+        got, produced = [], set()
+        for t in st["tiles"]:
+            in0, nleaf, out, nint, koff, loff, nlvl, moff, nout, ooff = [int(x) for x in t]
+            assert 1 <= nleaf <= 64 and nint == nleaf - nout
+            assert nlvl <= 3 if si == 0 else nout == 1  # only the first stage cuts its tiles
+            outs = st["outs"][ooff:ooff + nout]
+            assert len(set(outs)) == nout and (outs < nleaf + nint).all()
+            prev_end = 0
+            for d in st["micro"][moff:moff + nleaf]:
+                start, shape = int(d & 0xff), int(d >> 8)
+                size = 1 if shape == 0 else 2 if shape == 1 else 3
+                assert start == prev_end and 0 <= shape <= 3
+                got.extend(range(in0 + start, in0 + start + size))
+                prev_end = start + size
+            produced.update(range(out, out + nout))
+        assert len(got) == len(set(got)) and set(got) == want
+        want = produced
+    assert want == {pl["root_slot"]}
 
 
 def test_multirank_plan_shapes(ca):
