@@ -134,6 +134,7 @@ _SIGS = {
     "cedr_device_count": (C.c_int, []),
     "cedr_malloc": (_vp, [C.c_size_t]),
     "cedr_free": (None, [_vp]),
+    "cedr_caas_bind_arrays": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "cedr_memcpy_h2d": (C.c_int, [_vp, _vp, C.c_size_t]),
     "cedr_memcpy_d2h": (C.c_int, [_vp, _vp, C.c_size_t]),
     "cedr_memcpy_d2d_async": (C.c_int, [_vp, _vp, C.c_size_t, _vp]),
@@ -543,6 +544,14 @@ class CAAS(_CDR):
     def set_Qm_source(self, qm_src):
         self._src = qm_src
         _chk(lib().cedr_caas_set_Qm_source(self.h, _ptr(qm_src)))
+
+    def bind_arrays(self, Qm, Qm_min, Qm_max, Qm_prev=None):
+        """Zero-copy mode: run() limits the caller's [tracer][cell] device arrays in place
+        (Qm is overwritten with the result); bind_arrays(None, None, None) switches back."""
+        _chk(lib().cedr_caas_bind_arrays(self.h, _ptr(Qm) if Qm is not None else None,
+                                         _ptr(Qm_min) if Qm_min is not None else None,
+                                         _ptr(Qm_max) if Qm_max is not None else None,
+                                         _ptr(Qm_prev) if Qm_prev is not None else None), "bind_arrays")
 
     def _copy(self, row0, src, nrows):
         op = self.get_device_op()

@@ -25,6 +25,11 @@ struct CAASHip::Impl {
   Real* recv = nullptr;
   size_t send_sz = 0, recv_sz = 0;
   const Real* qm_src = nullptr;
+  // bind_arrays: the caller's [tracer][cell] arrays, limited in place (null = internal buffer)
+  Real* b_qm = nullptr;
+  const Real* b_min = nullptr;
+  const Real* b_max = nullptr;
+  const Real* b_prev = nullptr;
 };
 
 CAASHip::CAASHip (const mpi::Parallel::Ptr& p, const Int nlclcells,
@@ -121,6 +126,14 @@ const CAASHip::DeviceOp& CAASHip::get_device_op () { return o; }
 
 void CAASHip::set_stream (hipStream_t stream) { m_->stream = stream; }
 void CAASHip::set_Qm_source (const Real* qm_src) { m_->qm_src = qm_src; }
+
+void CAASHip::bind_arrays (Real* Qm, const Real* Qm_min, const Real* Qm_max, const Real* Qm_prev) {
+  cedr_throw_if(Qm && ( ! Qm_min || ! Qm_max), "bind_arrays needs Qm_min and Qm_max with Qm");
+  cedr_throw_if(Qm && o.need_conserve_ && ! Qm_prev,
+                "bind_arrays needs Qm_prev: a declared tracer conserves");
+  cedr_throw_if(Qm && user_reducer_, "bind_arrays is not supported with a UserAllReducer");
+  m_->b_qm = Qm; m_->b_min = Qm_min; m_->b_max = Qm_max; m_->b_prev = Qm_prev;
+}
 const Real* CAASHip::send_data () const { return m_->send; }
 const Real* CAASHip::recv_data () const { return m_->recv; }
 
@@ -134,8 +147,14 @@ void CAASHip::reduce_locally () {  // :129-201
                                                   m_->send, m_->stream));
     return;
   }
-  cedr_k_check(cedr_hip_caas_reduce_local(m_->probs.data(), nt, o.nlclcells_, o.need_conserve_,
-                                          o.d_, m_->qm_src, m_->partials.data(), m_->stream));
+  if (m_->b_qm)
+    cedr_k_check(cedr_hip_caas_reduce_local_arrays(m_->probs.data(), nt, o.nlclcells_, o.need_conserve_,
+                                                   m_->qm_src ? m_->qm_src : m_->b_qm, m_->b_qm,
+                                                   m_->b_min, m_->b_max, m_->b_prev,
+                                                   m_->partials.data(), m_->stream));
+  else
+    cedr_k_check(cedr_hip_caas_reduce_local(m_->probs.data(), nt, o.nlclcells_, o.need_conserve_,
+                                            o.d_, m_->qm_src, m_->partials.data(), m_->stream));
   cedr_k_check(cedr_hip_caas_sum_partials(nt, o.nlclcells_, m_->partials.data(), m_->send,
                                           m_->stream));
 }
@@ -146,8 +165,12 @@ void CAASHip::reduce_globally () {  // :203-209
 }
 
 void CAASHip::finish_locally () {  // :211-253
-  cedr_k_check(cedr_hip_caas_finish_local(get_num_tracers(), o.nlclcells_, o.d_, m_->recv,
-                                          m_->stream));
+  if (m_->b_qm)
+    cedr_k_check(cedr_hip_caas_finish_local_arrays(get_num_tracers(), o.nlclcells_, m_->b_qm, m_->b_min,
+                                                   m_->b_max, m_->recv, m_->stream));
+  else
+    cedr_k_check(cedr_hip_caas_finish_local(get_num_tracers(), o.nlclcells_, o.d_, m_->recv,
+                                            m_->stream));
 }
 
 void CAASHip::run () {  // :258-270

@@ -80,6 +80,10 @@ public:
   // values still land in the data buffer. Same arithmetic and traffic as the
   // in-place form; lets a caller keep its own Qm untouched.
   void set_Qm_source(const Real* qm_src);
+  // Zero-copy mode: run() limits the caller's own [tracer][cell] device arrays
+  // in place -- Qm is overwritten with the result -- instead of the internal SoA buffer, so no
+  // set_Qm / get_Qm pass is needed. Qm == nullptr returns to the internal buffer.
+  void bind_arrays(Real* Qm, const Real* Qm_min, const Real* Qm_max, const Real* Qm_prev);
   const Real* send_data () const;
   const Real* recv_data () const;
 

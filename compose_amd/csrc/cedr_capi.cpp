@@ -331,6 +331,13 @@ int cedr_caas_get_num_tracers (void* h) { return CA(h).get_num_tracers(); }
 int cedr_caas_run (void* h) { CEDR_TRY CA(h).run(); return 0; CEDR_CATCH(-1) }
 int cedr_caas_set_stream (void* h, cedr_stream_t s) { CA(h).set_stream(s); return 0; }
 int cedr_caas_set_Qm_source (void* h, const double* src) { CA(h).set_Qm_source(src); return 0; }
+int cedr_caas_bind_arrays (void* h, double* Qm, const double* Qm_min, const double* Qm_max,
+                           const double* Qm_prev) {
+  CEDR_TRY
+  CA(h).bind_arrays(Qm, Qm_min, Qm_max, Qm_prev);
+  return 0;
+  CEDR_CATCH(1)
+}
 int cedr_caas_get_device_op (void* h, cedr_caas_device_op* out) {
   const auto& o = CA(h).get_device_op();
   out->d = o.d_; out->nlclcells = o.nlclcells_; out->nt = o.nt_;

@@ -978,18 +978,21 @@ __device__ __forceinline__ void block_sum4 (double v[4], double* sm /* [4][4] */
 template <int VEC>
 __global__ __launch_bounds__(kBlock)
 void caas_reduce_kernel (const int32_t* __restrict__ probs, const int nt, const int n,
-                         const int need_conserve, double* __restrict__ d,
-                         const double* __restrict__ qm_src, double* __restrict__ partials) {
+                         const int need_conserve, const double* __restrict__ qm_in,
+                         double* __restrict__ qm_out, const double* __restrict__ qm_min,
+                         const double* __restrict__ qm_max, const double* __restrict__ qm_prev,
+                         double* __restrict__ partials) {
   __shared__ double sm[16];
   const int k = blockIdx.y, c = blockIdx.x, nchunks = gridDim.x;
   const size_t N = n;
-  double* __restrict__ qm = d + (1 + k)*N;
-  const double* __restrict__ qin = qm_src ? qm_src + k*N : qm;
-  const double* __restrict__ qlo = d + (1 + nt + k)*N;
-  const double* __restrict__ qhi = d + (1 + 2*static_cast<size_t>(nt) + k)*N;
+  // Arrays are [tracer][cell]: the reference's SoA buffer rows (cedr_caas_inl.hpp:22-34)
+  // or the caller's own arrays, bound in place.
+  double* __restrict__ qm = qm_out + k*N;
+  const double* __restrict__ qin = qm_in + k*N;
+  const double* __restrict__ qlo = qm_min + k*N;
+  const double* __restrict__ qhi = qm_max + k*N;
   const bool conserve = (probs[k] & CONSERVE) != 0;
-  const double* __restrict__ qpv = (need_conserve && conserve) ?
-    d + (1 + 3*static_cast<size_t>(nt) + k)*N : nullptr;
+  const double* __restrict__ qpv = (need_conserve && conserve) ? qm_prev + k*N : nullptr;
   const int beg = c*kCaasChunk, end = min(n, beg + kCaasChunk);
   double acc[4] = {0, 0, 0, 0};
   if (VEC == 2) {
@@ -1085,7 +1088,8 @@ __global__ void caas_reduce_accum_kernel (const int32_t* __restrict__ probs, con
 // reference cedr_caas.cpp:217-252 (adjust_Qm). grid = (nchunks, nt).
 template <int VEC>
 __global__ __launch_bounds__(kBlock)
-void caas_finish_kernel (const int nt, const int n, double* __restrict__ d,
+void caas_finish_kernel (const int nt, const int n, double* __restrict__ qm_io,
+                         const double* __restrict__ qm_min, const double* __restrict__ qm_max,
                          const double* __restrict__ recv) {
   const int k = blockIdx.y, c = blockIdx.x;
   const double clip_sum = recv[k], sum = recv[nt + k];
@@ -1102,8 +1106,8 @@ void caas_finish_kernel (const int nt, const int n, double* __restrict__ d,
   if ( ! (fac > 0)) return;
   fac = m/fac;
   const size_t N = n;
-  double* __restrict__ qm = d + (1 + k)*N;
-  const double* __restrict__ bnd = d + (1 + (toward_max ? 2 : 1)*static_cast<size_t>(nt) + k)*N;
+  double* __restrict__ qm = qm_io + k*N;
+  const double* __restrict__ bnd = (toward_max ? qm_max : qm_min) + k*N;
   const int beg = c*kCaasChunk, end = min(n, beg + kCaasChunk);
   if (VEC == 2) {
     typedef double __attribute__((ext_vector_type(2))) d2;
@@ -1363,20 +1367,37 @@ int cedr_hip_qlt_get_Qm (int32_t nt, const int32_t* trcr_r2l, int64_t stride, in
 
 int32_t cedr_hip_caas_nchunks (int32_t n) { return (n + kCaasChunk - 1)/kCaasChunk; }
 
+int cedr_hip_caas_reduce_local_arrays (const int32_t* probs, int32_t nt, int32_t n,
+                                       int need_conserve, const double* qm_in, double* qm_out,
+                                       const double* qm_min, const double* qm_max,
+                                       const double* qm_prev, double* partials,
+                                       cedr_stream_t stream) {
+  ProfScope ps(K_CAAS_REDUCE, n, stream);
+  const dim3 grid(cedr_hip_caas_nchunks(n), nt);
+  bool vec = n % 2 == 0;
+  for (const void* p : {static_cast<const void*>(qm_in), static_cast<const void*>(qm_out),
+                        static_cast<const void*>(qm_min), static_cast<const void*>(qm_max),
+                        static_cast<const void*>(qm_prev)})
+    if (p && reinterpret_cast<uintptr_t>(p) % 16) vec = false;
+  if (vec)
+    hipLaunchKernelGGL(caas_reduce_kernel<2>, grid, dim3(kBlock), 0, stream, probs, nt, n,
+                       need_conserve, qm_in, qm_out, qm_min, qm_max, qm_prev, partials);
+  else
+    hipLaunchKernelGGL(caas_reduce_kernel<1>, grid, dim3(kBlock), 0, stream, probs, nt, n,
+                       need_conserve, qm_in, qm_out, qm_min, qm_max, qm_prev, partials);
+  return launch_status();
+}
+
 int cedr_hip_caas_reduce_local (const int32_t* probs, int32_t nt, int32_t n, int need_conserve,
                                 double* d, const double* qm_src, double* partials,
                                 cedr_stream_t stream) {
-  ProfScope ps(K_CAAS_REDUCE, n, stream);
-  const dim3 grid(cedr_hip_caas_nchunks(n), nt);
-  const bool vec = n % 2 == 0 && reinterpret_cast<uintptr_t>(d) % 16 == 0 &&
-    ( ! qm_src || reinterpret_cast<uintptr_t>(qm_src) % 16 == 0);
-  if (vec)
-    hipLaunchKernelGGL(caas_reduce_kernel<2>, grid, dim3(kBlock), 0, stream, probs, nt, n,
-                       need_conserve, d, qm_src, partials);
-  else
-    hipLaunchKernelGGL(caas_reduce_kernel<1>, grid, dim3(kBlock), 0, stream, probs, nt, n,
-                       need_conserve, d, qm_src, partials);
-  return launch_status();
+  const size_t N = n;
+  double* const qm = d + N;
+  return cedr_hip_caas_reduce_local_arrays(probs, nt, n, need_conserve, qm_src ? qm_src : qm, qm,
+                                           d + (1 + static_cast<size_t>(nt))*N,
+                                           d + (1 + 2*static_cast<size_t>(nt))*N,
+                                           need_conserve ? d + (1 + 3*static_cast<size_t>(nt))*N : nullptr,
+                                           partials, stream);
 }
 
 int cedr_hip_caas_sum_partials (int32_t nt, int32_t n, const double* partials, double* send,
@@ -1398,16 +1419,27 @@ int cedr_hip_caas_reduce_local_accum (const int32_t* probs, int32_t nt, int32_t 
   return launch_status();
 }
 
-int cedr_hip_caas_finish_local (int32_t nt, int32_t n, double* d, const double* recv,
-                                cedr_stream_t stream) {
+int cedr_hip_caas_finish_local_arrays (int32_t nt, int32_t n, double* qm, const double* qm_min,
+                                       const double* qm_max, const double* recv,
+                                       cedr_stream_t stream) {
   ProfScope ps(K_CAAS_FINISH, n, stream);
   const dim3 grid(cedr_hip_caas_nchunks(n), nt);
-  const bool vec = n % 2 == 0 && reinterpret_cast<uintptr_t>(d) % 16 == 0;
+  const bool vec = n % 2 == 0 && reinterpret_cast<uintptr_t>(qm) % 16 == 0 &&
+    reinterpret_cast<uintptr_t>(qm_min) % 16 == 0 && reinterpret_cast<uintptr_t>(qm_max) % 16 == 0;
   if (vec)
-    hipLaunchKernelGGL(caas_finish_kernel<2>, grid, dim3(kBlock), 0, stream, nt, n, d, recv);
+    hipLaunchKernelGGL(caas_finish_kernel<2>, grid, dim3(kBlock), 0, stream, nt, n, qm, qm_min,
+                       qm_max, recv);
   else
-    hipLaunchKernelGGL(caas_finish_kernel<1>, grid, dim3(kBlock), 0, stream, nt, n, d, recv);
+    hipLaunchKernelGGL(caas_finish_kernel<1>, grid, dim3(kBlock), 0, stream, nt, n, qm, qm_min,
+                       qm_max, recv);
   return launch_status();
+}
+
+int cedr_hip_caas_finish_local (int32_t nt, int32_t n, double* d, const double* recv,
+                                cedr_stream_t stream) {
+  const size_t N = n;
+  return cedr_hip_caas_finish_local_arrays(nt, n, d + N, d + (1 + static_cast<size_t>(nt))*N,
+                                           d + (1 + 2*static_cast<size_t>(nt))*N, recv, stream);
 }
 
 void cedr_hip_profile_start (void) {

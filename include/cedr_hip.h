@@ -128,6 +128,14 @@ int32_t cedr_hip_caas_nchunks(int32_t n);
 int cedr_hip_caas_reduce_local(const int32_t* probs, int32_t nt, int32_t n, int need_conserve,
                                double* d, const double* qm_src, double* partials,
                                cedr_stream_t stream);
+/* The same on separate [tracer][cell] arrays (row stride n) instead of the one SoA
+ * buffer: a caller that already holds Qm, Qm_min, Qm_max, Qm_prev in that layout is
+ * limited IN PLACE (qm_in == qm_out), with no pack / unpack pass.
+ * qm_prev may be NULL when need_conserve is 0. */
+int cedr_hip_caas_reduce_local_arrays(const int32_t* probs, int32_t nt, int32_t n, int need_conserve,
+                                      const double* qm_in, double* qm_out, const double* qm_min,
+                                      const double* qm_max, const double* qm_prev, double* partials,
+                                      cedr_stream_t stream);
 int cedr_hip_caas_sum_partials(int32_t nt, int32_t n, const double* partials, double* send,
                                cedr_stream_t stream);
 /* User-reducer branch (cedr_caas.cpp:137-168): per-group partial sums in the
@@ -138,6 +146,8 @@ int cedr_hip_caas_reduce_local_accum(const int32_t* probs, int32_t nt, int32_t n
 /* CAAS::finish_locally (cedr_caas.cpp:211-253). recv[4*nt]. */
 int cedr_hip_caas_finish_local(int32_t nt, int32_t n, double* d, const double* recv,
                                cedr_stream_t stream);
+int cedr_hip_caas_finish_local_arrays(int32_t nt, int32_t n, double* qm, const double* qm_min,
+                                      const double* qm_max, const double* recv, cedr_stream_t stream);
 /* Bulk CAAS::DeviceOp::set_Qm / get_Qm (cedr_caas_inl.hpp:22-42) are plain
  * copies into/out of d because the layouts coincide: use hipMemcpyAsync. */
 
@@ -263,6 +273,10 @@ int cedr_caas_get_num_tracers(void* caas);
 int cedr_caas_run(void* caas);
 int cedr_caas_set_stream(void* caas, cedr_stream_t stream);
 int cedr_caas_set_Qm_source(void* caas, const double* qm_src);
+/* Zero-copy mode: run() limits the caller's [tracer][cell] arrays in place (Qm is
+ * overwritten with the result); NULL Qm returns to the internal buffer. */
+int cedr_caas_bind_arrays(void* caas, double* Qm, const double* Qm_min, const double* Qm_max,
+                          const double* Qm_prev);
 typedef struct { double* d; int nlclcells; int nt; int need_conserve; } cedr_caas_device_op;
 int cedr_caas_get_device_op(void* caas, cedr_caas_device_op* out);
 int cedr_caas_get_recv(void* caas, const double** recv_dev);

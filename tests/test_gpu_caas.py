@@ -82,3 +82,30 @@ def test_caas_errors(gpu):
         c.declare_tracer(7, 1)  # rhomidx > 0
     with pytest.raises(ca.CedrError):
         c.end_tracer_declarations()  # 0 tracers, cedr_caas.cpp:62
+
+
+@pytest.mark.parametrize("ncells", [1, 2, 777, 4096, 10001])
+def test_caas_bound_arrays_in_place(gpu, oracle, ncells):
+    """Zero-copy mode: CAAS limits the caller's own [tracer][cell] arrays
+    in place and gives bit-for-bit what the packed path gives (same kernels, same order)."""
+    ca = gpu
+    trs = R.caas_tracers(R.tracers_vector())
+    types = [t.problem_type for t in trs]
+    v = R.make_values(trs, ncells, seed=31 + ncells)
+    packed = common.run_hip_caas(ca, ncells, types, v)
+    c = ca.CAAS(ca.Parallel.self_(), ncells)
+    for t in types:
+        c.declare_tracer(t, 0)
+    c.end_tracer_declarations()
+    c.finish_setup()
+    d = [ca.DeviceArray.from_numpy(a) for a in (v.Qm, v.Qm_min, v.Qm_max, v.Qm_prev)]
+    c.bind_arrays(d[0], d[1], d[2], d[3])
+    c.run()
+    ca.synchronize()
+    got = d[0].numpy(v.Qm.shape)
+    assert np.array_equal(got, packed)
+    assert np.array_equal(d[1].numpy(v.Qm.shape), v.Qm_min)  # inputs untouched
+    want, _ = common.run_oracle_caas(oracle, [ncells], types, v)
+    assert np.abs(got - want).max() <= 1e-13 * max(np.abs(want).max(), 1e-300)
+    with pytest.raises(ca.CedrError):
+        c.bind_arrays(d[0], d[1], d[2], None)  # conserving tracers need Qm_prev
