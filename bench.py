@@ -333,9 +333,18 @@ def main():
     out_buf = torch.empty_like(Qm)
     t_set = timed_sync(lambda: qlt.set_Qm(Qm, Qm_min, Qm_max, Qm_prev))
     t_get = timed_sync(lambda: qlt.get_Qm(out_buf))
+    # Zero-copy mode: the first-stage kernels sweep the caller's arrays themselves.
+    t_run_packed = timed_sync(qlt.run)
+    qlt.bind_arrays(rhom, Qm, Qm_min, Qm_max, Qm_prev, out_buf)
+    t_run_bound = timed_sync(qlt.run)
+    qlt.bind_arrays(None, None, None, None, None, None)
     pack = {"qlt_set_Qm_ms": 1e3 * t_set, "qlt_set_Qm_GBs": 64.0 * n * nt / t_set / 1e9,
             "qlt_get_Qm_ms": 1e3 * t_get, "qlt_get_Qm_GBs": 16.0 * n * nt / t_get / 1e9,
-            "note": "bulk [tracer][cell] arrays <-> field-major QLT buffers; CAAS reads caller arrays in place"}
+            "qlt_run_ms": 1e3 * t_run_packed,
+            "qlt_set_run_get_ms": 1e3 * (t_set + t_run_packed + t_get),
+            "qlt_zero_copy_run_ms": 1e3 * t_run_bound,
+            "note": "bulk [tracer][cell] arrays <-> field-major QLT buffers; with bind_arrays QLT::run "
+                    "reads and writes the caller's arrays itself (no set_Qm / get_Qm pass), as CAAS does"}
     del out_buf
 
     ok = None

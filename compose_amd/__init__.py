@@ -135,6 +135,7 @@ _SIGS = {
     "cedr_malloc": (_vp, [C.c_size_t]),
     "cedr_free": (None, [_vp]),
     "cedr_caas_bind_arrays": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    "cedr_qlt_bind_arrays": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "cedr_memcpy_h2d": (C.c_int, [_vp, _vp, C.c_size_t]),
     "cedr_memcpy_d2h": (C.c_int, [_vp, _vp, C.c_size_t]),
     "cedr_memcpy_d2d_async": (C.c_int, [_vp, _vp, C.c_size_t, _vp]),
@@ -496,6 +497,13 @@ class QLT(_CDR):
 
     def get_Qm(self, out):
         _chk(lib().cedr_qlt_get_Qm_bulk(self.h, _ptr(out)), "get_Qm")
+
+    def bind_arrays(self, rhom, Qm, Qm_min, Qm_max, Qm_prev, Qm_out):
+        """Zero-copy mode: run() reads the caller's device arrays (rhom[cell]; the others
+        [tracer][cell]) and writes the limited masses to Qm_out (may be Qm). rhom=None switches back."""
+        f = lambda x: _ptr(x) if x is not None else None
+        _chk(lib().cedr_qlt_bind_arrays(self.h, f(rhom), f(Qm), f(Qm_min), f(Qm_max), f(Qm_prev), f(Qm_out)),
+             "bind_arrays")
 
     def metadata(self):
         nt = self.get_num_tracers()

@@ -218,6 +218,13 @@ int cedr_qlt_metadata (void* h, int* trcr2prob, int* bidx2trcr, int* trcr2bidx, 
   }
   return 0;
 }
+int cedr_qlt_bind_arrays (void* h, const double* rhom, const double* Qm, const double* Qm_min,
+                          const double* Qm_max, const double* Qm_prev, double* Qm_out) {
+  CEDR_TRY
+  Q(h).bind_arrays(rhom, Qm, Qm_min, Qm_max, Qm_prev, Qm_out);
+  return 0;
+  CEDR_CATCH(1)
+}
 void* cedr_qlt_nodesets (void* h) { return &static_cast<QltBox*>(h)->ns; }
 
 // ----------------------------------------------------------------------- plan

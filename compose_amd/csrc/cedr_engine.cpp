@@ -75,11 +75,16 @@ void TreeEngine::upload () {
   uploaded_ = true;
 }
 
+bool TreeEngine::first_stage_takes_rows () const {
+  return ! plan_.local.empty() && ! plan_.local[0].micro.empty();
+}
+
 void TreeEngine::up (int32_t nfields, const uint8_t* op_dev, double* data, bool zero_init,
-                     hipStream_t stream) {
+                     hipStream_t stream, const double* const* in_rows) {
   cedr_throw_if( ! uploaded_, "TreeEngine::upload was not called");
-  for (const auto& st : local_)
-    cedr_k_check(cedr_hip_tree_up(&st->h, nfields, op_dev, stride_, data, zero_init, stream));
+  for (size_t i = 0; i < local_.size(); ++i)
+    cedr_k_check(cedr_hip_tree_up_rows(&local_[i]->h, nfields, op_dev, stride_, data,
+                                       i == 0 ? in_rows : nullptr, zero_init, stream));
   if (top_.empty()) return;
   const int32_t P = plan_.nranks, nb = plan_.nb_max;
   if (nfields > xfields_) {

@@ -41,8 +41,12 @@ public:
   // Leaves->root over 'nfields' fields of 'data' (field-major, stride()).
   // After it returns (stream ordered) data[f*stride + root_slot] holds the
   // global root's record on every rank.
+  // in_rows (optional, device table of nfields row pointers): the first local stage reads
+  // its inputs from in_rows[f][slot] instead of data (zero-copy mode).
   void up(int32_t nfields, const uint8_t* op_dev, double* data, bool zero_init,
-          hipStream_t stream);
+          hipStream_t stream, const double* const* in_rows = nullptr);
+  // Whether the first local stage can read through a row table (it must be a micro stage).
+  bool first_stage_takes_rows () const;
 
   const std::vector<std::unique_ptr<DeviceStage> >& local_stages () const { return local_; }
   const std::vector<std::unique_ptr<DeviceStage> >& top_stages () const { return top_; }

@@ -417,11 +417,15 @@ __device__ __forceinline__ double micro_up_sum (const int shape, const double a,
   return shape <= 0 ? a : (shape == 1 ? t : r);
 }
 
-template <int FT>
+// ROWS: the tile's INPUT rows come from a table of per-field base pointers
+// (in_rows[f] + slot) instead of data + f*stride + slot -- the caller's own
+// [tracer][cell] arrays in zero-copy mode. Outputs always go to 'data'.
+template <int FT, bool ROWS>
 __global__ __launch_bounds__(kBlock)
 void tree_up_micro_kernel (const cedr_hip_stage st, const int nfields,
                            const uint8_t* __restrict__ op, const int64_t stride,
-                           double* __restrict__ data, const int zero_init, const int pitch) {
+                           double* __restrict__ data, const double* const* __restrict__ in_rows,
+                           const int zero_init, const int pitch) {
   static_assert(FT == 8*kNW || FT == 4*kNW || FT == 2*kNW,
                 "the prefetch wait macros are written for 2, 4 or 8 rows per wave");
   extern __shared__ double lds[];
@@ -433,25 +437,39 @@ void tree_up_micro_kernel (const cedr_hip_stage st, const int nfields,
   const int nleaf = tile.nleaf;
   const int nchunks = (nfields + FT - 1)/FT;
   const Micro m = get_micro(st, tile, lane);
-  const double* __restrict__ src0 = data + tile.in0 + m.start;
+  const int64_t cell0 = tile.in0 + m.start;
+  const double* __restrict__ src0 = data + cell0;
   constexpr int NR = FT/kNW;
-  // The per-field combine rule and the tile's output node ids, staged in LDS:
-  // any ordinary global load inside the chunk loop would make the chunk wait
-  // (vmcnt is in-order) for the next chunk's prefetch issued just before.
-  int32_t* const opL = reinterpret_cast<int32_t*>(v + static_cast<size_t>(FT)*pitch);
+  // The per-field combine rule, the tile's output node ids and (ROWS) the row
+  // table, staged in LDS: any ordinary global load inside the chunk loop would
+  // make the chunk wait (vmcnt is in-order) for the next chunk's prefetch issued
+  // just before.
+  const double** const rowsL = reinterpret_cast<const double**>(v + static_cast<size_t>(FT)*pitch);
+  int32_t* const opL = reinterpret_cast<int32_t*>(rowsL + (ROWS ? nfields : 0));
   int32_t* const outL = opL + nfields;
   for (int i = threadIdx.x; i < nfields; i += kBlock) opL[i] = op[i];
   for (int i = threadIdx.x; i < tile.nout; i += kBlock) outL[i] = st.outs[tile.outs_off + i];
+  if (ROWS) for (int i = threadIdx.x; i < nfields; i += kBlock) rowsL[i] = in_rows[i];
 
   // Cells past a micro-subtree's size are loaded and ignored (the shape decides
   // what enters a result); rows past the last field re-read the last one.
   const double* const plast = src0 + static_cast<size_t>(nfields - 1)*stride;
-  auto load = [&] (const int c, d2v (&ab)[NR], double (&cc)[NR]) {
-    const double* prow = src0 + static_cast<size_t>(c*FT + wave)*stride;
+  // 'staged': the LDS copy of the row table is visible (not yet for the first chunk)
+  auto load = [&] (const int c, d2v (&ab)[NR], double (&cc)[NR], const bool staged) {
+    if (ROWS) {
 #pragma unroll
-    for (int r = 0; r < NR; ++r) {
-      asm_load_cells(ab[r], cc[r], prow <= plast ? prow : plast);
-      prow += static_cast<size_t>(kNW)*stride;
+      for (int r = 0; r < NR; ++r) {
+        int f = c*FT + wave + kNW*r;
+        if (f > nfields - 1) f = nfields - 1;
+        asm_load_cells(ab[r], cc[r], (staged ? rowsL[f] : in_rows[f]) + cell0);
+      }
+    } else {
+      const double* prow = src0 + static_cast<size_t>(c*FT + wave)*stride;
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        asm_load_cells(ab[r], cc[r], prow <= plast ? prow : plast);
+        prow += static_cast<size_t>(kNW)*stride;
+      }
     }
   };
 
@@ -462,7 +480,7 @@ void tree_up_micro_kernel (const cedr_hip_stage st, const int nfields,
 #endif
   d2v cab[NR], nab[NR];
   double ccc[NR], ncc[NR];
-  load(blockIdx.y, cab, ccc);  // blockIdx.y < nchunks by construction of the grid
+  load(blockIdx.y, cab, ccc, false);  // blockIdx.y < nchunks by construction of the grid
   stage_tile_meta(st, tile, kidsL, lvlL);
   const int ff = threadIdx.x & (FT - 1);
   double* const vf = v + ff*pitch;
@@ -474,7 +492,7 @@ void tree_up_micro_kernel (const cedr_hip_stage st, const int nfields,
 
   for (int c = blockIdx.y; c < nchunks; c += gridDim.y) {
     const int cn = c + gridDim.y;
-    load(cn < nchunks ? cn : c, nab, ncc);  // the last chunk re-reads itself: keeps the count static
+    load(cn < nchunks ? cn : c, nab, ncc, true);  // the last chunk re-reads itself: keeps the count static
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
       const int fr = c*FT + wave + kNW*r;
@@ -600,10 +618,14 @@ void micro_solves (const int shape, const bool any2, const bool any3, const int 
 # define CEDR_MICRO_TW 2  // tracers per wave and chunk in the micro down sweep
 #endif
 constexpr int kCellRho = 12;  // LDS doubles per micro-subtree: {rh, w, q} of u, v, p, t
-template <int TW>
+// ROWS (zero-copy mode, first stage): the cells' input rows come from in_rows[l2r field]
+// and their results go to out_rows[bulk tracer index] instead of l2r / r2l rows.
+template <int TW, bool ROWS>
 __global__ __launch_bounds__(kBlock, CEDR_MICRO_WAVES)
 void qlt_down_micro_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st,
-                            double* __restrict__ l2r, double* __restrict__ r2l, const int pitch) {
+                            double* __restrict__ l2r, double* __restrict__ r2l,
+                            const double* const* __restrict__ in_rows,
+                            double* const* __restrict__ out_rows, const int pitch) {
   constexpr int TT = kNW*TW;  // tracers per chunk: TW per wave for the register part
   extern __shared__ double lds[];
   const cedr_hip_tile tile = st.tiles[blockIdx.x];
@@ -616,6 +638,9 @@ void qlt_down_micro_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st
   double* const rq = rw + MN;
   double* const cellrho = rq + MN;            // [kCellRho][kWave]
   double* const recs = cellrho + kCellRho*kWave;
+  // row tables staged in LDS (after the records), see tree_up_micro_kernel
+  const double** const inL = reinterpret_cast<const double**>(recs + static_cast<size_t>(TT)*pitch);
+  double** const outL = reinterpret_cast<double**>(recs + static_cast<size_t>(TT)*pitch) + (ROWS ? L.l2rndps : 0);
   const int nleaf = tile.nleaf;
   const int64_t S = L.stride;
   const bool prefer = L.prefer_mass_con != 0;
@@ -627,13 +652,27 @@ void qlt_down_micro_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st
 
   // Input records {lo, orig, hi} of this lane's cells for tracer bi (see
   // qlt_down_kernel for which l2r fields they are).
-  auto load = [&] (const int bi, double (&buf)[3][3]) {
+  // 'staged': the LDS copy of the row table is visible (not yet for the first chunk)
+  auto load = [&] (const int bi, double (&buf)[3][3], const bool staged) {
     bool sp = false;
     int field = 0;
     if (bi < nt) {
       const int pt = L.bidx_prob[bi];
       sp = (pt & SHAPEPRESERVE) != 0;
       field = L.bidx_l2r[bi] + (sp ? 0 : ((pt & CONSISTENT) ? 1 : 0));
+    }
+    if (ROWS) {
+      const double* const* rows = staged ? inL : in_rows;
+      if (sp) {
+        load_roles(rows[field] + tile.in0, ro, buf[0][0], buf[1][0], buf[2][0]);
+        load_roles(rows[field + 1] + tile.in0, ro, buf[0][1], buf[1][1], buf[2][1]);
+        load_roles(rows[field + 2] + tile.in0, ro, buf[0][2], buf[1][2], buf[2][2]);
+      } else {
+        load_roles(rows[field] + tile.in0, ro, buf[0][1], buf[1][1], buf[2][1]);
+        buf[0][0] = buf[1][0] = buf[2][0] = 0.0;
+        buf[0][2] = buf[1][2] = buf[2][2] = 0.0;
+      }
+      return;
     }
     const double* __restrict__ s0 = l2r + static_cast<size_t>(field)*S + tile.in0;
     if (sp) {
@@ -654,7 +693,11 @@ void qlt_down_micro_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st
 #endif
   double cur[TW][3][3];  // [tracer of this wave][role u,v,p][lo, orig, hi]
 #pragma unroll
-  for (int s = 0; s < TW; ++s) load(blockIdx.y*TT + wave + kNW*s, cur[s]);
+  for (int s = 0; s < TW; ++s) load(blockIdx.y*TT + wave + kNW*s, cur[s], false);
+  if (ROWS) {
+    for (int i = threadIdx.x; i < L.l2rndps; i += kBlock) inL[i] = in_rows[i];
+    for (int i = threadIdx.x; i < nt; i += kBlock) outL[i] = out_rows[i];
+  }
 
   // Densities of this lane's micro-subtree: roles u, v, p, the inner pair t and
   // the root, with 1/rhom and 1/(1/rhom) of everything that can be a kid.
@@ -664,7 +707,7 @@ void qlt_down_micro_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st
   // either way), and the eight divisions per micro-subtree happen once, not per wave.
   if (wave == 0) {
     double rh[4];
-    load_roles(l2r + tile.in0, ro, rh[0], rh[1], rh[2]);
+    load_roles((ROWS ? in_rows[0] : l2r) + tile.in0, ro, rh[0], rh[1], rh[2]);
     if (m.shape < 0) rh[0] = 1.0;
     if (m.shape < 1) rh[1] = 1.0;
     if (m.shape < 2) rh[2] = 1.0;
@@ -702,7 +745,7 @@ void qlt_down_micro_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st
   for (int c = blockIdx.y; c < nchunks; c += gridDim.y) {
     if (c != static_cast<int>(blockIdx.y)) {
 #pragma unroll
-      for (int s = 0; s < TW; ++s) load(c*TT + wave + kNW*s, cur[s]);
+      for (int s = 0; s < TW; ++s) load(c*TT + wave + kNW*s, cur[s], true);
     }
 
     // ---- this wave's tracers: micro-subtree sums in registers, root records to LDS
@@ -823,7 +866,7 @@ void qlt_down_micro_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st
       else
         micro_solves<false>(m.shape, any2, any3, ptw, rr, ku, kv, kp, kt, cur[s], T, RR, Xr, qlw, qhw, prefer,
                             Xu, Xv, Xp);
-      store_roles(r2l + static_cast<size_t>(rbw)*S + tile.in0, ro, Xu, Xv, Xp);
+      store_roles((ROWS ? outL[biw] : r2l + static_cast<size_t>(rbw)*S) + tile.in0, ro, Xu, Xv, Xp);
       if (t_onlyw) {
         double* __restrict__ dst = r2l + static_cast<size_t>(rbw)*S + tile.in0 + m.start;
         double* __restrict__ l0p = l2r + static_cast<size_t>(L.bidx_l2r[biw])*S + tile.in0 + m.start;
@@ -1227,20 +1270,34 @@ extern "C" {
 
 int cedr_hip_tree_up (const cedr_hip_stage* st, int32_t nfields, const uint8_t* op,
                       int64_t stride, double* data, int zero_init, cedr_stream_t stream) {
+  return cedr_hip_tree_up_rows(st, nfields, op, stride, data, nullptr, zero_init, stream);
+}
+
+int cedr_hip_tree_up_rows (const cedr_hip_stage* st, int32_t nfields, const uint8_t* op,
+                           int64_t stride, double* data, const double* const* in_rows,
+                           int zero_init, cedr_stream_t stream) {
   ProfScope ps(K_TREE_UP, st->ntiles, stream);
   if (st->ntiles == 0 || nfields == 0) return 0;
   if (st->max_nleaf > 256) return static_cast<int>(hipErrorInvalidValue);
+  if (in_rows && ! st->micro) return static_cast<int>(hipErrorInvalidValue);
   const int pitch = pitch_for(st->max_nodes);
   const size_t lds = sizeof(double)*(meta_doubles(st) + static_cast<size_t>(kUpFT)*pitch) +
+    (in_rows ? sizeof(double*)*static_cast<size_t>(nfields) : 0) +   // row table
     sizeof(int32_t)*static_cast<size_t>(nfields + 2 + kWave);  // + op table, + output node ids
   if (lds > 160*1024) return static_cast<int>(hipErrorInvalidValue);
   const dim3 grid(st->ntiles, chunk_split(st->ntiles, (nfields + kUpFT - 1)/kUpFT, kSplitUp));
-  if (st->micro) {
+  if (st->micro && in_rows) {
     if (st->max_nleaf > kWave) return static_cast<int>(hipErrorInvalidValue);
-    int e = set_lds_limit(tree_up_micro_kernel<kUpFT>, lds);
+    int e = set_lds_limit(tree_up_micro_kernel<kUpFT, true>, lds);
     if (e) return e;
-    hipLaunchKernelGGL((tree_up_micro_kernel<kUpFT>), grid, dim3(kBlock), lds, stream,
-                       *st, nfields, op, stride, data, zero_init, pitch);
+    hipLaunchKernelGGL((tree_up_micro_kernel<kUpFT, true>), grid, dim3(kBlock), lds, stream,
+                       *st, nfields, op, stride, data, in_rows, zero_init, pitch);
+  } else if (st->micro) {
+    if (st->max_nleaf > kWave) return static_cast<int>(hipErrorInvalidValue);
+    int e = set_lds_limit(tree_up_micro_kernel<kUpFT, false>, lds);
+    if (e) return e;
+    hipLaunchKernelGGL((tree_up_micro_kernel<kUpFT, false>), grid, dim3(kBlock), lds, stream,
+                       *st, nfields, op, stride, data, in_rows, zero_init, pitch);
   } else if (st->max_nleaf <= 128) {
     int e = set_lds_limit(tree_up_kernel<kUpFT, 2>, lds);
     if (e) return e;
@@ -1257,22 +1314,38 @@ int cedr_hip_tree_up (const cedr_hip_stage* st, int32_t nfields, const uint8_t* 
 
 int cedr_hip_qlt_down (const cedr_hip_qlt_layout* lay, const cedr_hip_stage* st,
                        double* l2r, double* r2l, cedr_stream_t stream) {
+  return cedr_hip_qlt_down_rows(lay, st, l2r, r2l, nullptr, nullptr, stream);
+}
+
+int cedr_hip_qlt_down_rows (const cedr_hip_qlt_layout* lay, const cedr_hip_stage* st,
+                            double* l2r, double* r2l, const double* const* in_rows,
+                            double* const* out_rows, cedr_stream_t stream) {
   ProfScope ps(K_QLT_DOWN, st->ntiles, stream);
   if (st->ntiles == 0) return 0;
   if (st->max_nleaf > 256) return static_cast<int>(hipErrorInvalidValue);
+  if (( ! in_rows) != ( ! out_rows) || (in_rows && ! st->micro))
+    return static_cast<int>(hipErrorInvalidValue);
   const size_t mn = st->max_nodes;
   const int pitch = pitch_for(4*st->max_nodes);
   if (st->micro) {
     if (st->max_nleaf > kWave) return static_cast<int>(hipErrorInvalidValue);
     constexpr int TW = CEDR_MICRO_TW, TTm = kNW*TW;
     const size_t ldsm = sizeof(double)*(meta_doubles(st) + 3*mn + kCellRho*kWave +
-                                        static_cast<size_t>(TTm)*pitch);
+                                        static_cast<size_t>(TTm)*pitch) +
+      (in_rows ? sizeof(double*)*static_cast<size_t>(lay->l2rndps + lay->nt) : 0);
     if (ldsm > 160*1024) return static_cast<int>(hipErrorInvalidValue);
-    int e = set_lds_limit(qlt_down_micro_kernel<TW>, ldsm);
-    if (e) return e;
     const dim3 gridm(st->ntiles, chunk_split(st->ntiles, (lay->nt + TTm - 1)/TTm, kSplitDown));
-    hipLaunchKernelGGL(qlt_down_micro_kernel<TW>, gridm, dim3(kBlock), ldsm, stream,
-                       *lay, *st, l2r, r2l, pitch);
+    if (in_rows) {
+      int e = set_lds_limit(qlt_down_micro_kernel<TW, true>, ldsm);
+      if (e) return e;
+      hipLaunchKernelGGL((qlt_down_micro_kernel<TW, true>), gridm, dim3(kBlock), ldsm, stream,
+                         *lay, *st, l2r, r2l, in_rows, out_rows, pitch);
+    } else {
+      int e = set_lds_limit(qlt_down_micro_kernel<TW, false>, ldsm);
+      if (e) return e;
+      hipLaunchKernelGGL((qlt_down_micro_kernel<TW, false>), gridm, dim3(kBlock), ldsm, stream,
+                         *lay, *st, l2r, r2l, in_rows, out_rows, pitch);
+    }
     return launch_status();
   }
   const size_t lds = sizeof(double)*(meta_doubles(st) + 3*mn + static_cast<size_t>(kDownTT)*pitch);

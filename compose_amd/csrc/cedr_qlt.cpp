@@ -31,6 +31,18 @@ struct QLTHip::Impl {
   dev::Buffer<Int> trcr2prob, trcr2bl2r, trcr2br2l, bidx_prob, bidx_l2r, bidx_r2l;
   dev::Buffer<uint8_t> l2r_op;
   cedr_hip_qlt_layout lay;
+  // bind_arrays state: row tables on the device, the caller's arrays, tracers still packed
+  bool bound = false;
+  dev::Buffer<const Real*> in_rows;
+  dev::Buffer<Real*> out_rows;
+  const Real* b_rhom = nullptr;
+  const Real* b_qm = nullptr;
+  const Real* b_min = nullptr;
+  const Real* b_max = nullptr;
+  const Real* b_prev = nullptr;
+  Real* b_out = nullptr;
+  bool bound_rows = false;  // the kernels read / write the caller's rows directly
+  std::vector<Int> packed_tracers;  // caller indices of the t-only tracers
 };
 
 // ---- MetaData: reference cedr_qlt.cpp:85-157, cedr_qlt_inl.hpp:101-117 ----
@@ -270,21 +282,87 @@ void QLTHip::get_Qm_bulk (Real* Qm_out) const {
                                    o.r2l_data, Qm_out, d_->stream));
 }
 
+void QLTHip::bind_arrays (const Real* rhom, const Real* Qm, const Real* Qm_min, const Real* Qm_max,
+                          const Real* Qm_prev, Real* Qm_out) {
+  Impl& d = *d_;
+  cedr_throw_if( ! d.inited || ! o.l2r_data, "finish_setup was not called");
+  if ( ! rhom) { d.bound = false; return; }
+  cedr_throw_if( ! Qm || ! Qm_min || ! Qm_max || ! Qm_out, "bind_arrays: null array");
+  d.b_rhom = rhom; d.b_qm = Qm; d.b_min = Qm_min; d.b_max = Qm_max; d.b_prev = Qm_prev;
+  d.b_out = Qm_out;
+  d.bound = true;
+  // Without a micro first stage (a one-cell rank, or micro tiles switched off) run() packs
+  // and unpacks through the internal buffers instead: same interface, same results.
+  d.bound_rows = eng_->first_stage_takes_rows();
+  if ( ! d.bound_rows) return;
+  const Int nt = get_num_tracers();
+  const size_t n = nlclcells();
+  std::vector<const Real*> in(d.lay.l2rndps, nullptr);
+  std::vector<Real*> out(nt, nullptr);
+  in[0] = rhom;
+  d.packed_tracers.clear();
+  for (Int ti = 0; ti < nt; ++ti) {
+    const Int pt = md_.trcr2prob[ti], bl = md_.trcr2bl2r[ti];
+    const Real* const q = Qm + ti*n;
+    Int next;
+    if (pt & ProblemType::shapepreserve) {
+      in[bl] = Qm_min + ti*n; in[bl+1] = q; in[bl+2] = Qm_max + ti*n;
+      next = 3;
+    } else if (pt & ProblemType::consistent) {
+      // bounds are stored divided by rhom (cedr_qlt_inl.hpp:37-44): packed inside run()
+      for (Int k = 0; k < 3; ++k) in[bl+k] = o.l2r_data + static_cast<int64_t>(bl+k)*o.stride;
+      d.packed_tracers.push_back(ti);
+      next = 3;
+    } else {
+      in[bl] = q;
+      next = 1;
+    }
+    if (pt & ProblemType::conserve) {
+      cedr_throw_if( ! Qm_prev, "bind_arrays needs Qm_prev: tracer " << ti << " conserves");
+      const bool packed = ! (pt & ProblemType::shapepreserve) && (pt & ProblemType::consistent);
+      in[bl+next] = packed ? o.l2r_data + static_cast<int64_t>(bl+next)*o.stride : Qm_prev + ti*n;
+    }
+    out[md_.trcr2bidx[ti]] = Qm_out + ti*n;
+  }
+  for (const Real* p : in) cedr_throw_if( ! p, "bind_arrays: an l2r field has no source row");
+  d.in_rows.upload(in);
+  d.out_rows.upload(out);
+}
+
 // Leaves->root over the local stages, one all-gather, the replicated top
 // stages, root_compute, then the same stages root->leaves.
 void QLTHip::run () {
   Impl& d = *d_;
   cedr_throw_if( ! d.inited || ! o.l2r_data, "finish_setup was not called");
   hipStream_t s = d.stream;
-  eng_->up(d.lay.l2rndps, d.lay.l2r_op, d.l2r, false, s);
+  const bool rows_mode = d.bound && d.bound_rows;
+  if (d.bound && ! d.bound_rows) {
+    set_rhom_bulk(d.b_rhom);
+    set_Qm_bulk(d.b_qm, d.b_min, d.b_max, d.b_prev);
+  }
+  if (rows_mode && ! d.packed_tracers.empty()) {
+    // t-only tracers: their rows stay internal; pack them (they read rhom from field 0)
+    const size_t n = nlclcells();
+    cedr_k_check(cedr_hip_qlt_set_rhom(o.stride, nlclcells(), d.b_rhom, o.l2r_data, s));
+    for (const Int ti : d.packed_tracers)
+      cedr_k_check(cedr_hip_qlt_set_Qm(1, o.trcr2prob + ti, o.trcr2bl2r + ti, o.stride, nlclcells(),
+                                       d.b_qm + ti*n, d.b_min + ti*n, d.b_max + ti*n,
+                                       d.b_prev ? d.b_prev + ti*n : nullptr, o.l2r_data, s));
+  }
+  eng_->up(d.lay.l2rndps, d.lay.l2r_op, d.l2r, false, s, rows_mode ? d.in_rows.data() : nullptr);
   cedr_k_check(cedr_hip_qlt_root(&d.lay, eng_->get_plan().root_slot, d.l2r, d.r2l, s));
   const auto& top = eng_->top_stages();
   for (size_t i = top.size(); i > 0; --i)
     cedr_k_check(cedr_hip_qlt_down(&d.lay, &top[i-1]->h, d.l2r, d.r2l, s));
   eng_->top_to_local(d.lay.r2lndps, d.r2l, s);
   const auto& loc = eng_->local_stages();
-  for (size_t i = loc.size(); i > 0; --i)
-    cedr_k_check(cedr_hip_qlt_down(&d.lay, &loc[i-1]->h, d.l2r, d.r2l, s));
+  for (size_t i = loc.size(); i > 0; --i) {
+    const bool rows = rows_mode && i == 1;
+    cedr_k_check(cedr_hip_qlt_down_rows(&d.lay, &loc[i-1]->h, d.l2r, d.r2l,
+                                        rows ? d.in_rows.data() : nullptr,
+                                        rows ? d.out_rows.data() : nullptr, s));
+  }
+  if (d.bound && ! d.bound_rows) get_Qm_bulk(d.b_out);
 }
 
 }  // namespace qlt

@@ -97,6 +97,13 @@ public:
   void set_rhom_bulk(const Real* rhom);
   void set_Qm_bulk(const Real* Qm, const Real* Qm_min, const Real* Qm_max, const Real* Qm_prev);
   void get_Qm_bulk(Real* Qm_out) const;
+  // Zero-copy mode: run() sweeps the caller's own device arrays -- rhom[cell];
+  // Qm, Qm_min, Qm_max, Qm_prev [tracer][cell] in caller tracer order -- and writes the limited
+  // masses to Qm_out[tracer][cell] (may be Qm): no set_rhom / set_Qm / get_Qm pass at all. Only
+  // tracers whose bounds are stored as mixing ratios (consistent without shapepreserve) are
+  // still packed, by a small kernel inside run(). rhom == nullptr switches back.
+  void bind_arrays(const Real* rhom, const Real* Qm, const Real* Qm_min, const Real* Qm_max,
+                   const Real* Qm_prev, Real* Qm_out);
   const MetaData& metadata () const { return md_; }
   const tree::NodeSets& nodesets () const { return *ns_; }
   const engine::TreeEngine& tree_engine () const { return *eng_; }

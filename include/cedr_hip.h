@@ -77,6 +77,14 @@ typedef struct {
  * zero_init != 0 (then a node is 0 + kid0 + kid1, as the reference computes). */
 int cedr_hip_tree_up(const cedr_hip_stage* stage, int32_t nfields, const uint8_t* op,
                      int64_t stride, double* data, int zero_init, cedr_stream_t stream);
+/* The same with the stage's INPUT rows taken from a device table of per-field base
+ * pointers, in_rows[f][slot], instead of data[f*stride + slot] (outputs still go to
+ * data): the first stage reading the caller's own [tracer][cell] arrays, i.e. no
+ * set_Qm pack pass. Micro stages only; in_rows == NULL is
+ * cedr_hip_tree_up. */
+int cedr_hip_tree_up_rows(const cedr_hip_stage* stage, int32_t nfields, const uint8_t* op,
+                          int64_t stride, double* data, const double* const* in_rows,
+                          int zero_init, cedr_stream_t stream);
 
 /* Root->leaves sweep over one stage: re-forms the tile's node sums in LDS,
  * takes the tile root's assigned mass from r2l, solves every node problem
@@ -84,6 +92,13 @@ int cedr_hip_tree_up(const cedr_hip_stage* stage, int32_t nfields, const uint8_t
  * masses. Replaces QLT::r2l_solve_qp for all levels inside the stage. */
 int cedr_hip_qlt_down(const cedr_hip_qlt_layout* lay, const cedr_hip_stage* stage,
                       double* l2r, double* r2l, cedr_stream_t stream);
+/* The same for the first stage in zero-copy mode: the cells' l2r rows are
+ * in_rows[l2r field][cell] and their new masses go to out_rows[bulk index][cell]
+ * (no get_Qm unpack pass). Both tables are device arrays; both NULL is
+ * cedr_hip_qlt_down. */
+int cedr_hip_qlt_down_rows(const cedr_hip_qlt_layout* lay, const cedr_hip_stage* stage,
+                           double* l2r, double* r2l, const double* const* in_rows,
+                           double* const* out_rows, cedr_stream_t stream);
 
 /* QLT::root_compute (cedr_qlt.cpp:441-476). */
 int cedr_hip_qlt_root(const cedr_hip_qlt_layout* lay, int32_t root_slot,
@@ -236,6 +251,11 @@ int cedr_qlt_get_Qm_bulk(void* qlt, double* Qm_out);
 int cedr_qlt_metadata(void* qlt, int* trcr2prob, int* bidx2trcr, int* trcr2bidx,
                       int* trcr2bl2r, int* trcr2br2l, int* prob2trcrptr, int* prob2bl2r,
                       int* prob2br2l);
+/* Zero-copy mode: run() reads the caller's device arrays (rhom[cell]; the others
+ * [tracer][cell], caller tracer order) and writes the limited masses to Qm_out, which
+ * may be Qm itself. No set_rhom / set_Qm / get_Qm pass; NULL rhom switches back. */
+int cedr_qlt_bind_arrays(void* qlt, const double* rhom, const double* Qm, const double* Qm_min,
+                         const double* Qm_max, const double* Qm_prev, double* Qm_out);
 void* cedr_qlt_nodesets(void* qlt); /* borrowed NodeSets handle for cedr_ns_* */
 /* Execution plan (host copy), for inspection and for the CPU multi-rank tests.
  * cedr_plan_create builds one without touching a GPU; cedr_qlt_plan borrows

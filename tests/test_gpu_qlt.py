@@ -103,3 +103,32 @@ def test_qlt_interleaved_types_and_errors(gpu, oracle):
         q2.declare_tracer(7, 1)  # rhomidx > 0 (cedr_qlt.cpp:280)
     with pytest.raises(ca.CedrError):
         q2.declare_tracer(1, 0)  # conserve alone is invalid (cedr_qlt.cpp:94)
+
+
+@pytest.mark.parametrize("ncells", [1, 2, 3, 7, 111, 1000, 5000])
+@pytest.mark.parametrize("in_place", [False, True])
+def test_qlt_bound_arrays_zero_copy(gpu, oracle, ncells, in_place):
+    """Zero-copy mode: run() sweeps the caller's own [tracer][cell] arrays
+    and writes the masses to Qm_out (or over Qm): bit-for-bit the packed path's result, for
+    every problem type (the t-only tracers are the ones still packed inside run())."""
+    ca = gpu
+    trs = R.tracers_vector()
+    types = [t.problem_type for t in trs]
+    v = R.make_values(trs, ncells, seed=777 + ncells)
+    want = common.run_oracle_qlt(oracle, (False, False), ncells, 1, types, v)
+    q = common.make_hip_qlt(ca, ca.Tree.make_1d(ncells), ncells, types)
+    d = [ca.DeviceArray.from_numpy(a) for a in (v.rhom, v.Qm, v.Qm_min, v.Qm_max, v.Qm_prev)]
+    out = d[1] if in_place else ca.DeviceArray(v.Qm.size)
+    q.bind_arrays(d[0], d[1], d[2], d[3], d[4], out)
+    q.run()
+    ca.synchronize()
+    assert np.array_equal(out.numpy(v.Qm.shape), want)
+    if not in_place:
+        assert np.array_equal(d[1].numpy(v.Qm.shape), v.Qm)  # inputs untouched
+        q.run()  # a second run on the same inputs repeats the first
+        ca.synchronize()
+        assert np.array_equal(out.numpy(v.Qm.shape), want)
+    # back to the packed path on the same object
+    q.bind_arrays(None, None, None, None, None, None)
+    got = common.run_hip_qlt(ca, q, v)
+    assert np.array_equal(got, want)
