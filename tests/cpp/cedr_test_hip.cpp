@@ -160,6 +160,12 @@ static int check (const char* name, const std::vector<Tracer>& ts, const Values&
   return nerr;
 }
 
+// bind_arrays of the two CDRs: QLT writes to a separate output array, CAAS limits Qm in place.
+static void bind (cedr::qlt::QLT<>& q, Real* const* d) { q.bind_arrays(d[0], d[1], d[2], d[3], d[4], d[5]); }
+static void bind (cedr::caas::CAAS<>& c, Real* const* d) { c.bind_arrays(d[1], d[2], d[3], d[4]); }
+static const Real* result_of (cedr::qlt::QLT<>&, Real* const* d) { return d[5]; }
+static const Real* result_of (cedr::caas::CAAS<>&, Real* const* d) { return d[1]; }
+
 template <typename CDRT>
 static int drive (const char* name, CDRT& cdr, const std::vector<Tracer>& ts, int n, bool external_memory,
                   bool prefer) {
@@ -195,6 +201,17 @@ static int drive (const char* name, CDRT& cdr, const std::vector<Tracer>& ts, in
   HIP_OK(hipDeviceSynchronize());
   std::vector<Real> out((size_t) n*nt);
   HIP_OK(hipMemcpy(out.data(), d[5], N, hipMemcpyDeviceToHost));
+  int nzc = 0;
+  {  // zero-copy mode on the same arrays must reproduce the DeviceOp-driven result exactly
+    HIP_OK(hipMemset(d[5], 0, N));
+    bind(cdr, d);
+    cdr.run();
+    HIP_OK(hipDeviceSynchronize());
+    std::vector<Real> zc((size_t) n*nt);
+    HIP_OK(hipMemcpy(zc.data(), result_of(cdr, d), N, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < zc.size(); ++i) if (zc[i] != out[i]) ++nzc;
+    if (nzc) std::printf("FAIL %s: bind_arrays differs from the DeviceOp path in %d values\n", name, nzc);
+  }
   for (int k = 0; k < 6; ++k) (void) hipFree(d[k]);
   if (const char* dump = std::getenv("CEDR_TEST_DUMP")) {  // debugging aid: raw results of this run
     const std::string fn = std::string(dump) + "." + name;
@@ -203,7 +220,7 @@ static int drive (const char* name, CDRT& cdr, const std::vector<Tracer>& ts, in
       std::fclose(fp);
     }
   }
-  const int nerr = check(name, ts, v, out, prefer);
+  const int nerr = check(name, ts, v, out, prefer) + nzc;
   if (b1) { (void) hipFree(b1); (void) hipFree(b2); }
   return nerr;
 }
