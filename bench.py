@@ -320,7 +320,11 @@ def main():
     if dom:
         roofline = dict(bound="hbm", kernel=dom["kernel"], achieved=dom["achieved_GBs"],
                         peak=HBM_PEAK_GBS, unit="GB/s", frac=dom["frac"], traffic=dom.get("traffic"),
-                        avg_ms=dom["avg_ms"], algorithmic_bytes_per_launch=dom["algorithmic_bytes"])
+                        avg_ms=dom["avg_ms"], algorithmic_bytes_per_launch=dom["algorithmic_bytes"],
+                        launch="first stage: %d workgroups (tiles)" % dom["launch"],
+                        rocprof="every stage runs the same *_micro_kernel, so rocprofv3 --stats averages all "
+                                "stages under one name; profiles/*_kernel_stats_by_grid.csv splits the same "
+                                "trace by launch grid (tools/kernel_stats_by_grid.py)")
 
     # Pack / unpack either side of run() (reported apart from `value`).
     def timed_sync(fn, reps=5):
