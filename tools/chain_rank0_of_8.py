@@ -1,0 +1,37 @@
+import sys, time, ctypes as C
+sys.path.insert(0, '/root/repo'); sys.argv=['x']
+import torch, compose_amd as ca, bench
+dev = torch.device('cuda', 0); torch.zeros(1, device=dev)
+L = ca.lib()
+P, n, nt = 8, 1500000, 40
+def mk(par, ncells, world):
+    q = ca.QLT(par, ncells, ca.Tree.make_1d(ncells, world, False, False))
+    for _ in range(nt): q.declare_tracer(7, 0)
+    q.end_tracer_declarations(); q.finish_setup(); return q
+def ag(s, r, cnt, st):   # every "rank" contributes my data: stream-ordered device copies
+    for k in range(P):
+        L.cedr_memcpy_d2d_async(r + 8*cnt*k, s, 8*cnt, st)
+    return 0
+def ar(s, r, cnt, st):
+    if s != r: L.cedr_memcpy_d2d_async(r, s, 8*cnt, st)
+    return 0
+def timeit(f, reps=200):
+    for _ in range(20): f()
+    torch.cuda.synchronize(); t=time.perf_counter()
+    for _ in range(reps): f()
+    torch.cuda.synchronize(); return (time.perf_counter()-t)/reps*1e3
+qa = mk(ca.Parallel.self_(), n//P, 1)
+qb = mk(ca.Parallel.callbacks(0, P, ag, ar), n, P)
+for q in (qa, qb):
+    m = q.nlclcells()
+    rhom, Qm, lo, hi, prev = bench.gen_inputs(torch, m, nt, 1, dev)
+    q.set_rhom(rhom); q.set_Qm(Qm, lo, hi, prev)
+    st = torch.cuda.Stream(device=dev); q.set_stream(st.cuda_stream)
+print('single rank, 187.5k cells : %.4f ms' % timeit(qa.run))
+print('rank 0 of 8, 1.5M cells   : %.4f ms' % timeit(qb.run))
+ca.profile_start()
+for _ in range(20): qb.run()
+recs = ca.profile_stop()
+agg = {}
+for name, aux, ms in recs: agg.setdefault((name, aux), []).append(ms)
+for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])): print('  %-24s %-8d %.4f ms' % (k[0], k[1], sum(v)/len(v)))
