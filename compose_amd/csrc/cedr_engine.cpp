@@ -76,7 +76,7 @@ void TreeEngine::upload () {
 }
 
 bool TreeEngine::first_stage_takes_rows () const {
-  return ! plan_.local.empty() && ! plan_.local[0].micro.empty();
+  return ! plan_.local.empty() && ! plan_.local[0].micro.empty() && plan_.nlcl >= 3;
 }
 
 void TreeEngine::up (int32_t nfields, const uint8_t* op_dev, double* data, bool zero_init,
@@ -84,7 +84,7 @@ void TreeEngine::up (int32_t nfields, const uint8_t* op_dev, double* data, bool 
   cedr_throw_if( ! uploaded_, "TreeEngine::upload was not called");
   for (size_t i = 0; i < local_.size(); ++i)
     cedr_k_check(cedr_hip_tree_up_rows(&local_[i]->h, nfields, op_dev, stride_, data,
-                                       i == 0 ? in_rows : nullptr, zero_init, stream));
+                                       i == 0 ? in_rows : nullptr, plan_.nlcl, zero_init, stream));
   if (top_.empty()) return;
   const int32_t P = plan_.nranks, nb = plan_.nb_max;
   if (nfields > xfields_) {

@@ -425,7 +425,7 @@ __global__ __launch_bounds__(kBlock)
 void tree_up_micro_kernel (const cedr_hip_stage st, const int nfields,
                            const uint8_t* __restrict__ op, const int64_t stride,
                            double* __restrict__ data, const double* const* __restrict__ in_rows,
-                           const int zero_init, const int pitch) {
+                           const int nrow, const int zero_init, const int pitch) {
   static_assert(FT == 8*kNW || FT == 4*kNW || FT == 2*kNW,
                 "the prefetch wait macros are written for 2, 4 or 8 rows per wave");
   extern __shared__ double lds[];
@@ -437,7 +437,11 @@ void tree_up_micro_kernel (const cedr_hip_stage st, const int nfields,
   const int nleaf = tile.nleaf;
   const int nchunks = (nfields + FT - 1)/FT;
   const Micro m = get_micro(st, tile, lane);
-  const int64_t cell0 = tile.in0 + m.start;
+  // ROWS: a caller's row (nrow cells) has no padding behind its last cell, so a lane whose
+  // 3-cell load window would reach past it reads the window cshift cells earlier and
+  // picks its cells from the later window positions (fix_window).
+  const int cshift = ROWS ? max(0, tile.in0 + m.start + 2 - (nrow - 1)) : 0;
+  const int64_t cell0 = tile.in0 + m.start - cshift;
   const double* __restrict__ src0 = data + cell0;
   constexpr int NR = FT/kNW;
   // The per-field combine rule, the tile's output node ids and (ROWS) the row
@@ -497,9 +501,14 @@ void tree_up_micro_kernel (const cedr_hip_stage st, const int nfields,
     for (int r = 0; r < NR; ++r) {
       const int fr = c*FT + wave + kNW*r;
       const int orow = fr < nfields ? opL[fr] : 0;
+      double wa = cab[r].x, wb = cab[r].y;
+      const double wc = ccc[r];
+      if (ROWS) {  // window shifted back by cshift: cell a sits at position cshift, b at cshift + 1
+        wa = cshift == 0 ? wa : (cshift == 1 ? wb : wc);
+        wb = cshift == 0 ? wb : wc;
+      }
       const double val = (orow == 0 && ! zero_init) ?
-        micro_up_sum(m.shape, cab[r].x, cab[r].y, ccc[r]) :
-        micro_up(m.shape, orow, zero_init, cab[r].x, cab[r].y, ccc[r]);
+        micro_up_sum(m.shape, wa, wb, wc) : micro_up(m.shape, orow, zero_init, wa, wb, wc);
       if (lane < nleaf) v[(wave + kNW*r)*pitch + lane] = val;
     }
     const int f = c*FT + ff;
@@ -559,6 +568,17 @@ __device__ __forceinline__ void load_roles (const double* __restrict__ row, cons
                                             double& u, double& v, double& p) {
   const Pair uv = *reinterpret_cast<const Pair*>(row + r.oUV);
   u = uv.x;
+  v = uv.y;
+  p = row[r.oP];
+}
+
+// The same on a CALLER's row, which unlike the internal rows has no padding behind
+// its last cell: a lane whose (u, v) pair would reach past the row reads the pair
+// one cell earlier and takes its second half (ushift = 1). Still unconditional.
+__device__ __forceinline__ void load_roles_edge (const double* __restrict__ row, const Roles& r,
+                                                 const int ushift, double& u, double& v, double& p) {
+  const Pair uv = *reinterpret_cast<const Pair*>(row + r.oUV - ushift);
+  u = ushift ? uv.y : uv.x;
   v = uv.y;
   p = row[r.oP];
 }
@@ -625,7 +645,7 @@ __global__ __launch_bounds__(kBlock, CEDR_MICRO_WAVES)
 void qlt_down_micro_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st,
                             double* __restrict__ l2r, double* __restrict__ r2l,
                             const double* const* __restrict__ in_rows,
-                            double* const* __restrict__ out_rows, const int pitch) {
+                            double* const* __restrict__ out_rows, const int nrow, const int pitch) {
   constexpr int TT = kNW*TW;  // tracers per chunk: TW per wave for the register part
   extern __shared__ double lds[];
   const cedr_hip_tile tile = st.tiles[blockIdx.x];
@@ -649,6 +669,8 @@ void qlt_down_micro_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st
   const Micro m = get_micro(st, tile, lane);
   const Roles ro = get_roles(m);
   const bool any2 = __ballot(m.shape == 2) != 0, any3 = __ballot(m.shape == 3) != 0;
+  // ROWS: nrow = cells per caller row; see load_roles_edge
+  const int ushift = (ROWS && tile.in0 + ro.oUV + 1 > nrow - 1) ? 1 : 0;
 
   // Input records {lo, orig, hi} of this lane's cells for tracer bi (see
   // qlt_down_kernel for which l2r fields they are).
@@ -664,11 +686,11 @@ void qlt_down_micro_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st
     if (ROWS) {
       const double* const* rows = staged ? inL : in_rows;
       if (sp) {
-        load_roles(rows[field] + tile.in0, ro, buf[0][0], buf[1][0], buf[2][0]);
-        load_roles(rows[field + 1] + tile.in0, ro, buf[0][1], buf[1][1], buf[2][1]);
-        load_roles(rows[field + 2] + tile.in0, ro, buf[0][2], buf[1][2], buf[2][2]);
+        load_roles_edge(rows[field] + tile.in0, ro, ushift, buf[0][0], buf[1][0], buf[2][0]);
+        load_roles_edge(rows[field + 1] + tile.in0, ro, ushift, buf[0][1], buf[1][1], buf[2][1]);
+        load_roles_edge(rows[field + 2] + tile.in0, ro, ushift, buf[0][2], buf[1][2], buf[2][2]);
       } else {
-        load_roles(rows[field] + tile.in0, ro, buf[0][1], buf[1][1], buf[2][1]);
+        load_roles_edge(rows[field] + tile.in0, ro, ushift, buf[0][1], buf[1][1], buf[2][1]);
         buf[0][0] = buf[1][0] = buf[2][0] = 0.0;
         buf[0][2] = buf[1][2] = buf[2][2] = 0.0;
       }
@@ -707,7 +729,8 @@ void qlt_down_micro_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st
   // either way), and the eight divisions per micro-subtree happen once, not per wave.
   if (wave == 0) {
     double rh[4];
-    load_roles((ROWS ? in_rows[0] : l2r) + tile.in0, ro, rh[0], rh[1], rh[2]);
+    if (ROWS) load_roles_edge(in_rows[0] + tile.in0, ro, ushift, rh[0], rh[1], rh[2]);
+    else load_roles(l2r + tile.in0, ro, rh[0], rh[1], rh[2]);
     if (m.shape < 0) rh[0] = 1.0;
     if (m.shape < 1) rh[1] = 1.0;
     if (m.shape < 2) rh[2] = 1.0;
@@ -1270,16 +1293,16 @@ extern "C" {
 
 int cedr_hip_tree_up (const cedr_hip_stage* st, int32_t nfields, const uint8_t* op,
                       int64_t stride, double* data, int zero_init, cedr_stream_t stream) {
-  return cedr_hip_tree_up_rows(st, nfields, op, stride, data, nullptr, zero_init, stream);
+  return cedr_hip_tree_up_rows(st, nfields, op, stride, data, nullptr, 0, zero_init, stream);
 }
 
 int cedr_hip_tree_up_rows (const cedr_hip_stage* st, int32_t nfields, const uint8_t* op,
                            int64_t stride, double* data, const double* const* in_rows,
-                           int zero_init, cedr_stream_t stream) {
+                           int32_t nrow, int zero_init, cedr_stream_t stream) {
   ProfScope ps(K_TREE_UP, st->ntiles, stream);
   if (st->ntiles == 0 || nfields == 0) return 0;
   if (st->max_nleaf > 256) return static_cast<int>(hipErrorInvalidValue);
-  if (in_rows && ! st->micro) return static_cast<int>(hipErrorInvalidValue);
+  if (in_rows && ( ! st->micro || nrow < 3)) return static_cast<int>(hipErrorInvalidValue);
   const int pitch = pitch_for(st->max_nodes);
   const size_t lds = sizeof(double)*(meta_doubles(st) + static_cast<size_t>(kUpFT)*pitch) +
     (in_rows ? sizeof(double*)*static_cast<size_t>(nfields) : 0) +   // row table
@@ -1291,13 +1314,13 @@ int cedr_hip_tree_up_rows (const cedr_hip_stage* st, int32_t nfields, const uint
     int e = set_lds_limit(tree_up_micro_kernel<kUpFT, true>, lds);
     if (e) return e;
     hipLaunchKernelGGL((tree_up_micro_kernel<kUpFT, true>), grid, dim3(kBlock), lds, stream,
-                       *st, nfields, op, stride, data, in_rows, zero_init, pitch);
+                       *st, nfields, op, stride, data, in_rows, nrow, zero_init, pitch);
   } else if (st->micro) {
     if (st->max_nleaf > kWave) return static_cast<int>(hipErrorInvalidValue);
     int e = set_lds_limit(tree_up_micro_kernel<kUpFT, false>, lds);
     if (e) return e;
     hipLaunchKernelGGL((tree_up_micro_kernel<kUpFT, false>), grid, dim3(kBlock), lds, stream,
-                       *st, nfields, op, stride, data, in_rows, zero_init, pitch);
+                       *st, nfields, op, stride, data, in_rows, nrow, zero_init, pitch);
   } else if (st->max_nleaf <= 128) {
     int e = set_lds_limit(tree_up_kernel<kUpFT, 2>, lds);
     if (e) return e;
@@ -1314,16 +1337,16 @@ int cedr_hip_tree_up_rows (const cedr_hip_stage* st, int32_t nfields, const uint
 
 int cedr_hip_qlt_down (const cedr_hip_qlt_layout* lay, const cedr_hip_stage* st,
                        double* l2r, double* r2l, cedr_stream_t stream) {
-  return cedr_hip_qlt_down_rows(lay, st, l2r, r2l, nullptr, nullptr, stream);
+  return cedr_hip_qlt_down_rows(lay, st, l2r, r2l, nullptr, nullptr, 0, stream);
 }
 
 int cedr_hip_qlt_down_rows (const cedr_hip_qlt_layout* lay, const cedr_hip_stage* st,
                             double* l2r, double* r2l, const double* const* in_rows,
-                            double* const* out_rows, cedr_stream_t stream) {
+                            double* const* out_rows, int32_t nrow, cedr_stream_t stream) {
   ProfScope ps(K_QLT_DOWN, st->ntiles, stream);
   if (st->ntiles == 0) return 0;
   if (st->max_nleaf > 256) return static_cast<int>(hipErrorInvalidValue);
-  if (( ! in_rows) != ( ! out_rows) || (in_rows && ! st->micro))
+  if (( ! in_rows) != ( ! out_rows) || (in_rows && ( ! st->micro || nrow < 3)))
     return static_cast<int>(hipErrorInvalidValue);
   const size_t mn = st->max_nodes;
   const int pitch = pitch_for(4*st->max_nodes);
@@ -1339,12 +1362,12 @@ int cedr_hip_qlt_down_rows (const cedr_hip_qlt_layout* lay, const cedr_hip_stage
       int e = set_lds_limit(qlt_down_micro_kernel<TW, true>, ldsm);
       if (e) return e;
       hipLaunchKernelGGL((qlt_down_micro_kernel<TW, true>), gridm, dim3(kBlock), ldsm, stream,
-                         *lay, *st, l2r, r2l, in_rows, out_rows, pitch);
+                         *lay, *st, l2r, r2l, in_rows, out_rows, nrow, pitch);
     } else {
       int e = set_lds_limit(qlt_down_micro_kernel<TW, false>, ldsm);
       if (e) return e;
       hipLaunchKernelGGL((qlt_down_micro_kernel<TW, false>), gridm, dim3(kBlock), ldsm, stream,
-                         *lay, *st, l2r, r2l, in_rows, out_rows, pitch);
+                         *lay, *st, l2r, r2l, in_rows, out_rows, nrow, pitch);
     }
     return launch_status();
   }

@@ -360,7 +360,7 @@ void QLTHip::run () {
     const bool rows = rows_mode && i == 1;
     cedr_k_check(cedr_hip_qlt_down_rows(&d.lay, &loc[i-1]->h, d.l2r, d.r2l,
                                         rows ? d.in_rows.data() : nullptr,
-                                        rows ? d.out_rows.data() : nullptr, s));
+                                        rows ? d.out_rows.data() : nullptr, nlclcells(), s));
   }
   if (d.bound && ! d.bound_rows) get_Qm_bulk(d.b_out);
 }

@@ -80,10 +80,10 @@ int cedr_hip_tree_up(const cedr_hip_stage* stage, int32_t nfields, const uint8_t
 /* The same with the stage's INPUT rows taken from a device table of per-field base
  * pointers, in_rows[f][slot], instead of data[f*stride + slot] (outputs still go to
  * data): the first stage reading the caller's own [tracer][cell] arrays, i.e. no
- * set_Qm pack pass. Micro stages only; in_rows == NULL is
- * cedr_hip_tree_up. */
+ * set_Qm pack pass. Micro stages only. nrow (>= 3) = valid cells per
+ * row: nothing is read outside [row, row + nrow). in_rows == NULL is cedr_hip_tree_up. */
 int cedr_hip_tree_up_rows(const cedr_hip_stage* stage, int32_t nfields, const uint8_t* op,
-                          int64_t stride, double* data, const double* const* in_rows,
+                          int64_t stride, double* data, const double* const* in_rows, int32_t nrow,
                           int zero_init, cedr_stream_t stream);
 
 /* Root->leaves sweep over one stage: re-forms the tile's node sums in LDS,
@@ -94,11 +94,11 @@ int cedr_hip_qlt_down(const cedr_hip_qlt_layout* lay, const cedr_hip_stage* stag
                       double* l2r, double* r2l, cedr_stream_t stream);
 /* The same for the first stage in zero-copy mode: the cells' l2r rows are
  * in_rows[l2r field][cell] and their new masses go to out_rows[bulk index][cell]
- * (no get_Qm unpack pass). Both tables are device arrays; both NULL is
- * cedr_hip_qlt_down. */
+ * (no get_Qm unpack pass). Both tables are device arrays; nrow as above; both NULL
+ * is cedr_hip_qlt_down. */
 int cedr_hip_qlt_down_rows(const cedr_hip_qlt_layout* lay, const cedr_hip_stage* stage,
                            double* l2r, double* r2l, const double* const* in_rows,
-                           double* const* out_rows, cedr_stream_t stream);
+                           double* const* out_rows, int32_t nrow, cedr_stream_t stream);
 
 /* QLT::root_compute (cedr_qlt.cpp:441-476). */
 int cedr_hip_qlt_root(const cedr_hip_qlt_layout* lay, int32_t root_slot,

@@ -105,7 +105,9 @@ def test_qlt_interleaved_types_and_errors(gpu, oracle):
         q2.declare_tracer(1, 0)  # conserve alone is invalid (cedr_qlt.cpp:94)
 
 
-@pytest.mark.parametrize("ncells", [1, 2, 3, 7, 111, 1000, 5000])
+# (sizes chosen so that the last micro-subtree of the last tile has every shape: the
+# kernels may not read past the end of a caller row, which has no padding)
+@pytest.mark.parametrize("ncells", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 64, 65, 111, 193, 1000, 5000])
 @pytest.mark.parametrize("in_place", [False, True])
 def test_qlt_bound_arrays_zero_copy(gpu, oracle, ncells, in_place):
     """Zero-copy mode: run() sweeps the caller's own [tracer][cell] arrays
