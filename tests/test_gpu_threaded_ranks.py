@@ -9,6 +9,14 @@ import common
 import randomized as R
 import threaded_ranks as T
 
+
+def _bfb_local_leaves(tree, nleaf, rank):
+    """Global ids of a rank's leaves in the order BfbTreeAllReducer indexes its send buffer:
+    NodeSets levels[0].nodes (cedr_bfb_tree_allreduce.cpp:91-102) -- which is NOT always
+    QLT's local cell order (node offsets) when ownership cuts across subtrees."""
+    ns = tree.analyze(nleaf, rank)
+    return np.array([ns["nodes"][i][1] for i in ns["levels"][0]["nodes"]], dtype=np.int64)
+
 pytestmark = pytest.mark.gpu
 
 
@@ -62,3 +70,84 @@ def test_qlt_bound_arrays_ranks_as_threads(gpu, oracle):
         out[:, g] = d[1].numpy((len(types), len(g)))
     T.run_ranks(nranks, body)
     assert np.array_equal(out, want)
+
+
+@pytest.mark.parametrize("accum", [1, 4])
+def test_caas_with_bfb_user_reducer_is_decomposition_invariant(gpu, oracle, accum):
+    """The production pairing (north star): CAAS whose UserAllReducer is the BFB tree
+    all-reduce over element partials. The limited masses must be bit-identical on 1, 2, 4
+    and 8 ranks -- that is the point of the BFB reducer -- and agree with the oracle's CAAS."""
+    ca = gpu
+    ngroups = 96                      # leaves of the reducer's tree ("elements")
+    ncells = ngroups * accum          # cells per element = n_accum_in_place
+    trs = R.caas_tracers(R.tracers_vector())
+    types = [t.problem_type for t in trs]
+    nt = len(types)
+    v = R.make_values(trs, ncells, seed=accum)
+    results = {}
+    for nranks in (1, 2, 4, 8):
+        out = np.zeros_like(v.Qm)
+
+        def body(rank, comm):
+            par = comm.parallel(ca, rank)
+            tree = ca.Tree.make_1d(ngroups, nranks, False, False)
+            groups = _bfb_local_leaves(tree, ngroups, rank)
+            cells = (groups[:, None] * accum + np.arange(accum)[None, :]).ravel()
+            bfb = ca.BfbTreeAllReducer(par, tree, ngroups, 4 * nt)
+            assert bfb.nlocal() == len(groups)
+
+            def reducer(send, recv, nlocal, nfld):
+                assert nlocal == len(groups) and nfld == 4 * nt
+                bfb.allreduce(send, recv, True)  # CAAS emits (field, partial): the transposed layout
+                return 0
+            c = ca.CAAS(par, len(cells), reducer, accum)
+            for t in types:
+                c.declare_tracer(t, 0)
+            c.end_tracer_declarations()
+            c.finish_setup()
+            d = [ca.DeviceArray.from_numpy(a) for a in
+                 (v.rhom[cells], v.Qm[:, cells], v.Qm_min[:, cells], v.Qm_max[:, cells], v.Qm_prev[:, cells])]
+            c.set_rhom(d[0])
+            c.set_Qm(d[1], d[2], d[3], d[4])
+            c.run()
+            od = ca.DeviceArray(nt * len(cells))
+            c.get_Qm(od)
+            ca.synchronize()
+            out[:, cells] = od.numpy((nt, len(cells)))
+        T.run_ranks(nranks, body)
+        results[nranks] = out
+    for nranks in (2, 4, 8):
+        assert np.array_equal(results[nranks], results[1]), nranks
+    want, _ = common.run_oracle_caas(oracle, [ncells], types, v)
+    assert np.abs(results[1] - want).max() <= 1e-13 * np.abs(want).max()
+    assert R.check(trs, v, results[1], False, verbose=False)[0] == 0
+
+
+@pytest.mark.parametrize("nranks,ncell", [(2, 24), (3, 1000), (5, 1000), (8, 1000), (8, 8)])
+@pytest.mark.parametrize("transpose", [False, True])
+def test_bfb_allreduce_ranks_as_threads(gpu, oracle, nranks, ncell, transpose):
+    """BfbTreeAllReducer across ranks (cedr_bfb_tree_allreduce.cpp:79-159): every rank gets
+    the same bits, equal to the single-rank oracle sum over the same tree."""
+    ca = gpu
+    nfield = 5
+    rng = np.random.default_rng(ncell + nranks)
+    glob = rng.random((ncell, nfield))  # [leaf][field]
+    lay = lambda a: np.ascontiguousarray(a.T if transpose else a).ravel()
+    want = oracle.bfb_allreduce(oracle.Tree.make_1d(ncell, 1, False, False), ncell, 1, nfield, transpose,
+                                [lay(glob)])[0]
+    got = [None] * nranks
+
+    def body(rank, comm):
+        par = comm.parallel(ca, rank)
+        tree = ca.Tree.make_1d(ncell, nranks, False, False)
+        mine = _bfb_local_leaves(tree, ncell, rank)
+        b = ca.BfbTreeAllReducer(par, tree, ncell, nfield)
+        assert b.nlocal() == len(mine)
+        sd = ca.DeviceArray.from_numpy(lay(glob[mine]))
+        rd = ca.DeviceArray(nfield)
+        b.allreduce(sd, rd, transpose)
+        ca.synchronize()
+        got[rank] = rd.numpy()
+    T.run_ranks(nranks, body)
+    for r in range(nranks):
+        assert np.array_equal(got[r], want), r
