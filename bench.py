@@ -46,6 +46,9 @@ def parse():
     ap.add_argument("--comm", choices=["rccl", "gloo"], default="rccl",
                     help="data-path transport for N > 1: the library's RCCL communicator (default) or, "
                          "for rehearsals on one GPU, host-staged torch.distributed/gloo callbacks")
+    ap.add_argument("--caas-bfb", type=int, default=0, metavar="ACCUM",
+                    help="CAAS with the BFB tree all-reduce as its UserAllReducer (the production pairing): "
+                         "ACCUM cells per reducer leaf (n_accum_in_place), e.g. 4; 0 = CAAS's own all-reduce")
     ap.add_argument("--same-gpu", action="store_true",
                     help="rehearsal: every rank uses GPU 0 (needs --comm gloo)")
     return ap.parse_args()
@@ -140,6 +143,7 @@ def main():
     torch.zeros(1, device=device)  # initialise the HIP context before the library is used
 
     ncells, nt = a.ncells, a.ntracers
+    keep = []  # objects the callbacks refer to
 
     def make_cdrs(par, par2):
         tree = ca.Tree.make_1d(ncells, world, False, False)  # contiguous ownership, balanced
@@ -148,7 +152,17 @@ def main():
             qlt.declare_tracer(CST, 0)
         qlt.end_tracer_declarations()
         qlt.finish_setup()
-        caas = ca.CAAS(par2, qlt.nlclcells())
+        if a.caas_bfb:
+            acc = a.caas_bfb
+            if ncells % (acc * world):
+                raise SystemExit("--caas-bfb %d needs ncells divisible by %d" % (acc, acc * world))
+            btree = ca.Tree.make_1d(ncells // acc, world, False, False)
+            bfb = ca.BfbTreeAllReducer(par2, btree, ncells // acc, 4 * nt)
+            keep.append((btree, bfb))
+            # CAAS emits (field, partial) = the reducer's transposed layout
+            caas = ca.CAAS(par2, qlt.nlclcells(), lambda s, r, nl, nf: bfb.allreduce(s, r, True), acc)
+        else:
+            caas = ca.CAAS(par2, qlt.nlclcells())
         for _ in range(nt):
             caas.declare_tracer(CST, 0)
         caas.end_tracer_declarations()
@@ -294,7 +308,9 @@ def main():
     plan = qlt.plan()
     ntiles1 = len(plan["local"][0]["tiles"]) if plan["local"] else 0
     alg = {("tree_up_kernel", ntiles1): n * (32.0 * nt + 8), ("qlt_down_kernel", ntiles1): n * (32.0 * nt + 8),
-           ("caas_reduce_kernel", n): n * nt * 40.0, ("caas_finish_kernel", n): n * nt * 24.0}
+           ("caas_reduce_kernel", n): n * nt * 40.0, ("caas_finish_kernel", n): n * nt * 24.0,
+           # user-reducer variant: the same streams + 4 partial sums per group of caas_bfb cells
+           ("caas_reduce_accum_kernel", n): n * nt * (40.0 + 32.0 / max(a.caas_bfb, 1))}
     kernels = []
     for (name, aux), (cnt, tot) in sorted(per.items(), key=lambda kv: -kv[1][1]):
         avg_ms = tot / cnt
@@ -388,7 +404,9 @@ def main():
                                    "contiguous %d-way sharding" % (" on two concurrent streams" if streams else "",
                                                                    ncells, nt, world),
                        "ncells": ncells, "ntracers": nt, "cells_per_gpu": n,
-                       "transport": transport},
+                       "transport": transport,
+                       "caas_reducer": ("bfb_tree_allreduce, %d cells per leaf" % a.caas_bfb) if a.caas_bfb
+                       else "own all-reduce"},
             "qlt": {"ms_per_run": 1e3 * t_qlt, "updates_per_s": ncells * nt / t_qlt},
             "caas": {"ms_per_run": 1e3 * t_caas, "updates_per_s": ncells * nt / t_caas},
             "pack_unpack": pack, "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu,

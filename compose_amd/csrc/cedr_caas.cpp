@@ -140,11 +140,10 @@ const Real* CAASHip::recv_data () const { return m_->recv; }
 void CAASHip::reduce_locally () {  // :129-201
   const Int nt = get_num_tracers();
   if (user_reducer_) {
-    cedr_throw_if(m_->qm_src, "set_Qm_source is not supported with a UserAllReducer");
     cedr_k_check(cedr_hip_caas_reduce_local_accum(m_->probs.data(), nt, o.nlclcells_,
                                                   o.need_conserve_,
                                                   user_reducer_->n_accum_in_place(), o.d_,
-                                                  m_->send, m_->stream));
+                                                  m_->qm_src, m_->send, m_->stream));
     return;
   }
   if (m_->b_qm)

@@ -1122,7 +1122,8 @@ void caas_sum_partials_kernel (const int nchunks, const double* __restrict__ par
 // reference cedr_caas.cpp:140-168 (user-reducer branch): thread per (field, group).
 __global__ void caas_reduce_accum_kernel (const int32_t* __restrict__ probs, const int nt,
                                           const int n, const int need_conserve, const int na,
-                                          double* __restrict__ d, double* __restrict__ send) {
+                                          double* __restrict__ d, const double* __restrict__ qm_src,
+                                          double* __restrict__ send) {
   const int nacc = n/na;
   const int j = blockIdx.x*blockDim.x + threadIdx.x;
   const size_t N = n;
@@ -1133,7 +1134,7 @@ __global__ void caas_reduce_accum_kernel (const int32_t* __restrict__ probs, con
     double ac = 0, at = 0;
     for (int ai = 0; ai < na; ++ai) {
       const size_t i = static_cast<size_t>(na)*bi + ai;
-      const double Qm = d[os + i];
+      const double Qm = qm_src ? qm_src[static_cast<size_t>(k)*N + i] : d[os + i];
       const double term = (need_conserve && conserve) ? d[os + N*3*nt + i] : Qm;
       const double clip = rmin(d[os + N*2*nt + i], rmax(d[os + N*nt + i], Qm));
       d[os + i] = clip;
@@ -1148,6 +1149,63 @@ __global__ void caas_reduce_accum_kernel (const int32_t* __restrict__ probs, con
     double ae = 0;
     for (int ai = 0; ai < na; ++ai) ae += d[os + static_cast<size_t>(na)*bi + ai];
     send[static_cast<size_t>(nacc)*k + bi] = ae;
+  }
+}
+
+// The same sums with coalesced traffic (the kernel above mirrors the reference's
+// thread-per-group loop: at 16 cells per group it runs at a few % of HBM speed). A
+// workgroup streams sub-blocks of whole groups through LDS: every thread loads cells
+// the way caas_reduce_kernel does, clips, writes Qm back and parks {clip, term, min,
+// max} in LDS; then one thread per (quantity, group) adds the group's cells in the
+// reference's order, 0 + c0 + c1 + ..., so the partial sums a UserAllReducer sees
+// are bit-identical. LDS rows are padded by one double per group, which keeps the
+// group-strided reads of the second phase off a single bank.
+constexpr int kAccumSub = 1024;  // cells per sub-block (upper bound; a multiple of n_accum is used)
+constexpr int kAccumNsb = 4;     // sub-blocks per workgroup
+__global__ __launch_bounds__(kBlock)
+void caas_reduce_accum_lds_kernel (const int32_t* __restrict__ probs, const int nt, const int n,
+                                   const int need_conserve, const int na, const int sb,
+                                   double* __restrict__ d, const double* __restrict__ qm_src,
+                                   double* __restrict__ send) {
+  extern __shared__ double sm[];  // [4][sb + sb/na]
+  const int k = blockIdx.y;
+  const size_t N = n;
+  const int nacc = n/na;
+  double* __restrict__ qm = d + (1 + k)*N;
+  const double* __restrict__ qin = qm_src ? qm_src + k*N : qm;
+  const double* __restrict__ qlo = d + (1 + nt + k)*N;
+  const double* __restrict__ qhi = d + (1 + 2*static_cast<size_t>(nt) + k)*N;
+  const bool conserve = (probs[k] & CONSERVE) != 0;
+  const double* __restrict__ qpv = (need_conserve && conserve) ?
+    d + (1 + 3*static_cast<size_t>(nt) + k)*N : nullptr;
+  const int rowlen = sb + sb/na;
+  for (int b = 0; b < kAccumNsb; ++b) {
+    const int64_t beg = (static_cast<int64_t>(blockIdx.x)*kAccumNsb + b)*sb;
+    if (beg >= n) break;
+    const int cnt = static_cast<int>(min(static_cast<int64_t>(sb), n - beg));  // whole groups
+    for (int i = threadIdx.x; i < cnt; i += kBlock) {
+      // streamed once: non-temporal, as in caas_reduce_kernel
+      const double q = __builtin_nontemporal_load(qin + beg + i), lo = __builtin_nontemporal_load(qlo + beg + i),
+        hi = __builtin_nontemporal_load(qhi + beg + i);
+      const double cl = rmin(hi, rmax(lo, q));
+      qm[beg + i] = cl;
+      const int j = i + i/na;
+      sm[j] = cl;
+      sm[rowlen + j] = qpv ? __builtin_nontemporal_load(qpv + beg + i) : q;
+      sm[2*rowlen + j] = lo;
+      sm[3*rowlen + j] = hi;
+    }
+    __syncthreads();
+    const int ng = cnt/na;
+    const int g0 = static_cast<int>(beg/na);
+    for (int t = threadIdx.x; t < 4*ng; t += kBlock) {
+      const int q = t/ng, g = t - q*ng;
+      const double* __restrict__ v = sm + q*rowlen + g*(na + 1);
+      double acc = 0;
+      for (int ai = 0; ai < na; ++ai) acc += v[ai];
+      send[static_cast<size_t>(nacc)*(q*nt + k) + g0 + g] = acc;
+    }
+    __syncthreads();
   }
 }
 
@@ -1505,13 +1563,21 @@ int cedr_hip_caas_sum_partials (int32_t nt, int32_t n, const double* partials, d
 }
 
 int cedr_hip_caas_reduce_local_accum (const int32_t* probs, int32_t nt, int32_t n,
-                                      int need_conserve, int32_t na, double* d, double* send,
-                                      cedr_stream_t stream) {
+                                      int need_conserve, int32_t na, double* d,
+                                      const double* qm_src, double* send, cedr_stream_t stream) {
   ProfScope ps(K_CAAS_ACCUM, n, stream);
   if (na < 1 || n % na) return static_cast<int>(hipErrorInvalidValue);
+  if (na <= kAccumSub) {
+    const int sb = kAccumSub/na*na;
+    const size_t lds = sizeof(double)*4*static_cast<size_t>(sb + sb/na);
+    const int64_t per = static_cast<int64_t>(sb)*kAccumNsb;
+    hipLaunchKernelGGL(caas_reduce_accum_lds_kernel, dim3(static_cast<unsigned>((n + per - 1)/per), nt),
+                       dim3(kBlock), lds, stream, probs, nt, n, need_conserve, na, sb, d, qm_src, send);
+    return launch_status();
+  }
   const int total = 2*nt*(n/na);
   hipLaunchKernelGGL(caas_reduce_accum_kernel, dim3((total + kBlock - 1)/kBlock), dim3(kBlock), 0,
-                     stream, probs, nt, n, need_conserve, na, d, send);
+                     stream, probs, nt, n, need_conserve, na, d, qm_src, send);
   return launch_status();
 }
 

@@ -156,8 +156,8 @@ int cedr_hip_caas_sum_partials(int32_t nt, int32_t n, const double* partials, do
 /* User-reducer branch (cedr_caas.cpp:137-168): per-group partial sums in the
  * reference's send layout, send[nlclaccum*f + bi]. */
 int cedr_hip_caas_reduce_local_accum(const int32_t* probs, int32_t nt, int32_t n,
-                                     int need_conserve, int32_t n_accum_in_place, double* d,
-                                     double* send, cedr_stream_t stream);
+                                     int need_conserve, int32_t n_accum, double* d,
+                                     const double* qm_src, double* send, cedr_stream_t stream);
 /* CAAS::finish_locally (cedr_caas.cpp:211-253). recv[4*nt]. */
 int cedr_hip_caas_finish_local(int32_t nt, int32_t n, double* d, const double* recv,
                                cedr_stream_t stream);
