@@ -19,6 +19,11 @@ struct BfbTreeAllReducerHip::Impl {
   dev::Buffer<Real> bd;          // [nfield][stride]
   dev::Buffer<int32_t> leaf_slots, root_slot;
   dev::Buffer<uint8_t> op;       // all sums
+  // Transposed sends (field, leaf) whose leaf order is the slot order are swept in place:
+  // the first stage reads send's rows through a row table instead of a scattered copy.
+  bool identity = false;             // local leaf id == slot
+  dev::Buffer<const Real*> rows;     // [nfield] row pointers into the last send seen
+  const Real* rows_for = nullptr;
 };
 
 void BfbTreeAllReducerHip::init (const mpi::Parallel::Ptr& p, const tree::FlatTree& tree,
@@ -59,6 +64,8 @@ void BfbTreeAllReducerHip::finish_setup () {
   std::vector<int32_t> ls(nlocal_);
   for (Int i = 0; i < nlocal_; ++i) ls[i] = ns_->node_h(ns_->levels[0].nodes[i])->offset;
   m_->leaf_slots.upload(ls);
+  m_->identity = true;
+  for (Int i = 0; i < nlocal_; ++i) if (ls[i] != i) m_->identity = false;
   m_->root_slot.upload(std::vector<int32_t>(1, eng_->get_plan().root_slot));
   m_->op.upload(std::vector<uint8_t>(nfield_, 0));
 }
@@ -68,12 +75,23 @@ void BfbTreeAllReducerHip::allreduce (const Real* send, Real* recv, const bool t
   hipStream_t s = m_->stream;
   Real* const bd = m_->bd.data();
   const int64_t S = eng_->stride();
-  if (transpose)
+  const Real* const* in_rows = nullptr;
+  if (transpose && m_->identity && eng_->first_stage_takes_rows()) {
+    if (m_->rows_for != send) {  // (re)build the row table: rows of 'send' are nlocal apart
+      std::vector<const Real*> r(nfield_);
+      for (Int f = 0; f < nfield_; ++f) r[f] = send + static_cast<size_t>(f)*nlocal_;
+      cedr_hip_check(hipStreamSynchronize(s));  // a sweep still reading the old table?
+      m_->rows.upload(r);
+      m_->rows_for = send;
+    }
+    in_rows = m_->rows.data();
+  } else if (transpose) {
     cedr_k_check(cedr_hip_scatter_slots_fm(bd, S, nfield_, m_->leaf_slots.data(), nlocal_, send, s));
-  else
+  } else {
     cedr_k_check(cedr_hip_scatter_slots(bd, S, nfield_, m_->leaf_slots.data(), nlocal_, send, s));
+  }
   // Every node is 0 + kid0 + kid1, as in cedr_bfb_tree_allreduce.cpp:117-123.
-  eng_->up(nfield_, m_->op.data(), bd, true, s);
+  eng_->up(nfield_, m_->op.data(), bd, true, s, in_rows);
   // The root's record is the result on every rank (:68-76 read it back from
   // the first leaf after the root->leaves copies; the value is the same).
   cedr_k_check(cedr_hip_gather_slots(bd, S, nfield_, m_->root_slot.data(), 1, recv, s));

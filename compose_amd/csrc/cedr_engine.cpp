@@ -76,7 +76,13 @@ void TreeEngine::upload () {
 }
 
 bool TreeEngine::first_stage_takes_rows () const {
-  return ! plan_.local.empty() && ! plan_.local[0].micro.empty() && plan_.nlcl >= 3;
+  if (plan_.local.empty() || plan_.local[0].micro.empty() || plan_.nlcl < 3) return false;
+  // A cell that is itself a boundary root (its sibling belongs to another rank) is never the
+  // input of a local tile: the exchange reads its record straight from the internal buffer,
+  // which a row table bypasses. Rare (ownership cutting through a pair of cells): such ranks
+  // keep the packed path.
+  for (const int32_t s : plan_.my_root_slots) if (s < plan_.nlcl) return false;
+  return true;
 }
 
 void TreeEngine::up (int32_t nfields, const uint8_t* op_dev, double* data, bool zero_init,
