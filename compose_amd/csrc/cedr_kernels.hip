@@ -942,6 +942,32 @@ __global__ void scatter_slots_kernel (double* __restrict__ data, const int64_t s
   if (s >= 0) data[static_cast<size_t>(f)*stride + s] = in[idx];
 }
 
+// The same for many slots (the BFB reducer's leaf-major sends): a 32 x 32 tile goes
+// through LDS so that both the reads (along fields) and the writes (along slots, which
+// are consecutive for consecutive q in practice) are coalesced.
+__global__ __launch_bounds__(kBlock)
+void scatter_slots_tiled_kernel (double* __restrict__ data, const int64_t stride,
+                                 const int nfields, const int32_t* __restrict__ slots,
+                                 const int n, const double* __restrict__ in) {
+  __shared__ double tile[32][33];
+  const int q0 = blockIdx.x*32, f0 = blockIdx.y*32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int q = q0 + ty + 8*r, f = f0 + tx;
+    if (q < n && f < nfields) tile[ty + 8*r][tx] = in[static_cast<size_t>(q)*nfields + f];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int f = f0 + ty + 8*r, q = q0 + tx;
+    if (q < n && f < nfields) {
+      const int s = slots[q];
+      if (s >= 0) data[static_cast<size_t>(f)*stride + s] = tile[tx][ty + 8*r];
+    }
+  }
+}
+
 __global__ void scatter_slots_fm_kernel (double* __restrict__ data, const int64_t stride,
                                          const int nfields, const int32_t* __restrict__ slots,
                                          const int n, const double* __restrict__ in) {
@@ -1467,8 +1493,12 @@ int cedr_hip_scatter_slots (double* data, int64_t stride, int32_t nfields, const
                             int32_t n, const double* in, cedr_stream_t stream) {
   ProfScope ps(K_SCATTER, n, stream);
   if (n*nfields == 0) return 0;
-  hipLaunchKernelGGL(scatter_slots_kernel, dim3((n*nfields + kBlock - 1)/kBlock), dim3(kBlock), 0,
-                     stream, data, stride, nfields, slots, n, in);
+  if (n >= 1024)
+    hipLaunchKernelGGL(scatter_slots_tiled_kernel, dim3((n + 31)/32, (nfields + 31)/32), dim3(kBlock), 0,
+                       stream, data, stride, nfields, slots, n, in);
+  else
+    hipLaunchKernelGGL(scatter_slots_kernel, dim3((n*nfields + kBlock - 1)/kBlock), dim3(kBlock), 0,
+                       stream, data, stride, nfields, slots, n, in);
   return launch_status();
 }
 

@@ -6,7 +6,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("ncell", [1, 3, 24, 1000])
+@pytest.mark.parametrize("ncell", [1, 3, 24, 1000, 1025, 5000])
 @pytest.mark.parametrize("imbalanced", [False, True])
 @pytest.mark.parametrize("transpose", [False, True])
 def test_bfb_allreduce(gpu, oracle, ncell, imbalanced, transpose):
