@@ -239,6 +239,8 @@ def main():
         streams = (torch.cuda.Stream(device=device), torch.cuda.Stream(device=device))
         qlt.set_stream(streams[0].cuda_stream)
         caas.set_stream(streams[1].cuda_stream)
+        for _, bfb in keep:
+            bfb.set_stream(streams[1].cuda_stream)  # the reducer runs inside caas.run()
 
     def barrier():
         if world > 1:
@@ -290,6 +292,8 @@ def main():
         torch.cuda.synchronize()
         qlt.set_stream(None)
         caas.set_stream(None)
+        for _, bfb in keep:
+            bfb.set_stream(None)
     ca.profile_start()
     for _ in range(a.steps):
         step()

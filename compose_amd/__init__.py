@@ -131,6 +131,7 @@ _SIGS = {
     "cedr_bfb_free": (None, [_vp]),
     "cedr_bfb_nlocal": (C.c_int, [_vp]),
     "cedr_bfb_allreduce": (C.c_int, [_vp, _vp, _vp, C.c_int]),
+    "cedr_bfb_set_stream": (C.c_int, [_vp, _vp]),
     "cedr_device_count": (C.c_int, []),
     "cedr_malloc": (_vp, [C.c_size_t]),
     "cedr_free": (None, [_vp]),
@@ -610,6 +611,10 @@ class BfbTreeAllReducer:
 
     def allreduce(self, send, recv, transpose=False):
         _chk(lib().cedr_bfb_allreduce(self.h, _ptr(send), _ptr(recv), int(transpose)), "allreduce")
+
+    def set_stream(self, stream):
+        """hipStream_t (int / None) all work is enqueued on; inside CAAS.run use CAAS's stream."""
+        _chk(lib().cedr_bfb_set_stream(self.h, stream), "set_stream")
 
     def __del__(self):
         try:

@@ -367,6 +367,12 @@ int cedr_bfb_nlocal (void* h) { return static_cast<BfbBox*>(h)->b->nlocal(); }
 int cedr_bfb_allreduce (void* h, const double* send, double* recv, int transpose) {
   CEDR_TRY static_cast<BfbBox*>(h)->b->allreduce(send, recv, transpose != 0); return 0; CEDR_CATCH(-1)
 }
+int cedr_bfb_set_stream (void* h, cedr_stream_t stream) {
+  CEDR_TRY
+  static_cast<BfbBox*>(h)->b->set_stream(static_cast<hipStream_t>(stream));
+  return 0;
+  CEDR_CATCH(1)
+}
 
 // -------------------------------------------------------------- device helpers
 int cedr_device_count (void) {

@@ -306,6 +306,9 @@ void* cedr_bfb_create(void* parallel, void* tree, int nleaf, int nfield);
 void cedr_bfb_free(void* bfb);
 int cedr_bfb_nlocal(void* bfb);
 int cedr_bfb_allreduce(void* bfb, const double* send, double* recv, int transpose);
+/* All work of allreduce is enqueued on this stream (default: the null stream); a reducer
+ * used inside CAAS::run must use CAAS's stream. */
+int cedr_bfb_set_stream(void* bfb, cedr_stream_t stream);
 
 /* -- device memory helpers for hosts without their own HIP bindings ---------- */
 int cedr_device_count(void);
