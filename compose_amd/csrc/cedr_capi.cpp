@@ -235,11 +235,16 @@ void* cedr_plan_create (void* tree, int ncells, int my_rank, int nranks, int max
   const tree::FlatTree& t = static_cast<TreeBox*>(tree)->t;
   const auto ns = tree::analyze(my_rank, ncells, t);
   cedr_throw_if(ns->levels.empty() || ns->levels[0].nodes.empty(), "0 cells on this rank");
-  std::map<Int,Int> g2l;
-  for (const Int idx : ns->levels[0].nodes) g2l[ns->node_h(idx)->id] = ns->node_h(idx)->offset;
+  util::IdMap g2l;
+  g2l.reserve(ns->levels[0].nodes.size());
+  for (const Int idx : ns->levels[0].nodes) g2l.add(ns->node_h(idx)->id, ns->node_h(idx)->offset);
+  g2l.finish();
   std::vector<int32_t> leaf_slot(t.size(), -1);
   for (Int n = 0; n < t.size(); ++n)
-    if (t.nkids[n] == 0 && t.rank[n] == my_rank) leaf_slot[n] = g2l.at(static_cast<Int>(t.cellidx[n]));
+    if (t.nkids[n] == 0 && t.rank[n] == my_rank) {
+      leaf_slot[n] = g2l.find(static_cast<Int>(t.cellidx[n]));
+      cedr_throw_if(leaf_slot[n] < 0, "owned leaf missing from NodeSets");
+    }
   plan::Options o;
   if (max_tile_leaves > 0) o.max_tile_leaves = max_tile_leaves;
   if (max_tile_leaves < 0) { o.micro = false; if (max_tile_leaves < -1) o.max_tile_leaves = -max_tile_leaves; }

@@ -164,6 +164,11 @@ NodeSets::ConstPtr analyze (const Int my_rank, const Int& ncells, FlatTree t) {
   ns.levels.resize(depth);
 
   // reference cedr_tree.cpp:55-129 (level_schedule_and_collect), post-order.
+  {  // one allocation for the node pool: owned nodes + one placeholder per remote kid at most
+    size_t nown = 0;
+    for (Int n = 0; n < nn; ++n) if (t.rank[n] == my_rank) ++nown;
+    ns.reserve(std::min<size_t>(static_cast<size_t>(nn), 3*nown + 16));
+  }
   std::vector<Int> lvl(nn, 0), reserved(nn, -1);
   std::vector<char> need_parent(nn, 0);
   for (const Int n : order) {

@@ -48,6 +48,7 @@ struct NodeSets {
   Int nslots;
 
   Int alloc () { node_mem_.push_back(Node()); return static_cast<Int>(node_mem_.size()) - 1; }
+  void reserve (size_t n) { node_mem_.reserve(n); }
   Int nnode () const { return static_cast<Int>(node_mem_.size()); }
   Node* node_h (const Int& idx) { return &node_mem_[idx]; }
   const Node* node_h (const Int& idx) const { return &node_mem_[idx]; }
