@@ -100,3 +100,27 @@ def test_cnn_mass_check_behaviour_recorded_by_the_survey(oracle):
     assert seen, "expected the survey's `c nn` FAIL signature at >= 2k cells"
     assert all(pt == (R.CONSERVE | R.NONNEGATIVE) for pt, _ in seen)
     assert all(2e-14 <= rd <= 2e-13 for _, rd in seen)
+
+
+def test_qlt_and_caas_total_mass_agree(oracle):
+    """SURVEY.md 8(c) probe of the real reference: on cst tracers the total masses QLT and
+    CAAS hand back agree to 1e-15 relative (both conserve Sum Qm_prev)."""
+    import math
+    import common
+    import randomized as R
+    rng = np.random.default_rng(8)
+    n, nt = 1024, 4  # config A
+    trs = [R.Tracer(i, 7, 1) for i in range(nt)]
+    v = R.Values(nt, n)
+    v.rhom[:] = 0.5 * (1 + rng.random(n))
+    q_min = -0.75 + rng.random((nt, n)); q_max = q_min + rng.random((nt, n))
+    q = q_min + (q_max - q_min) * rng.random((nt, n))
+    v.Qm_min[:], v.Qm_max[:] = q_min * v.rhom, q_max * v.rhom
+    v.Qm_prev[:] = np.maximum(v.Qm_min, np.minimum(v.Qm_max, q * v.rhom))
+    for t in range(nt):
+        v.Qm[t] = v.Qm_prev[t][rng.permutation(n)]
+    a = common.run_oracle_qlt(oracle, (False, False), n, 1, [7] * nt, v)
+    b, _ = common.run_oracle_caas(oracle, [n], [7] * nt, v)
+    for t in range(nt):
+        ma, mb = math.fsum(a[t]), math.fsum(b[t])
+        assert abs(ma - mb) <= 1e-14 * math.fsum(np.abs(v.Qm_prev[t]))
