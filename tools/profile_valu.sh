@@ -12,7 +12,9 @@ import csv, glob, collections
 for f in glob.glob("gpurun_out/prof_valu/**/*counter_collection.csv", recursive=True):
     agg = collections.defaultdict(lambda: collections.defaultdict(float)); nd = collections.defaultdict(set)
     for r in csv.DictReader(open(f)):
-        k = (r["Kernel_Name"].split("(")[0][-36:], r["Grid_Size"])
+        import re as _re
+        _m = _re.search(r"(\w+_kernel)", r["Kernel_Name"])
+        k = (_m.group(1) if _m else r["Kernel_Name"][:30], r["Grid_Size"])
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); nd[k].add(r["Dispatch_Id"])
     for k, v in sorted(agg.items(), key=lambda kv: -kv[1].get("SQ_WAVE_CYCLES", 0))[:6]:
         n = len(nd[k]); w = v["SQ_WAVES"]/n
