@@ -49,6 +49,9 @@ def parse():
     ap.add_argument("--caas-bfb", type=int, default=0, metavar="ACCUM",
                     help="CAAS with the BFB tree all-reduce as its UserAllReducer (the production pairing): "
                          "ACCUM cells per reducer leaf (n_accum_in_place), e.g. 4; 0 = CAAS's own all-reduce")
+    ap.add_argument("--types", choices=["cst", "mix"], default="cst",
+                    help="QLT tracer problem types: all cst (BASELINE's metric) or the harness's six types "
+                         "cst, st, ct, t, nn, cnn in turn (diagnostic)")
     ap.add_argument("--same-gpu", action="store_true",
                     help="rehearsal: every rank uses GPU 0 (needs --comm gloo)")
     return ap.parse_args()
@@ -148,8 +151,9 @@ def main():
     def make_cdrs(par, par2):
         tree = ca.Tree.make_1d(ncells, world, False, False)  # contiguous ownership, balanced
         qlt = ca.QLT(par, ncells, tree)
-        for _ in range(nt):
-            qlt.declare_tracer(CST, 0)
+        mix = [7, 2, 5, 4, 8, 9]  # cst, s(t), ct, t, nn, cnn
+        for i in range(nt):
+            qlt.declare_tracer(CST if a.types == "cst" else mix[i % 6], 0)
         qlt.end_tracer_declarations()
         qlt.finish_setup()
         if a.caas_bfb:
