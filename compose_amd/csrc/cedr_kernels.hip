@@ -9,6 +9,7 @@
 #include <cfloat>
 #include <cstdint>
 #include <type_traits>
+#include <cstdlib>
 #include <vector>
 
 #include "../../include/cedr_hip.h"
@@ -1436,23 +1437,30 @@ int cedr_hip_qlt_down_rows (const cedr_hip_qlt_layout* lay, const cedr_hip_stage
   const int pitch = pitch_for(4*st->max_nodes);
   if (st->micro) {
     if (st->max_nleaf > kWave) return static_cast<int>(hipErrorInvalidValue);
-    constexpr int TW = CEDR_MICRO_TW, TTm = kNW*TW;
+    // Two builds: 2 tracers per wave (8 per chunk) or 1 (4 per chunk). A chunk costs the
+    // same whether it is full or not, and a 4-tracer chunk costs ~0.7 of an 8-tracer one
+    // (measured at 1.5M cells: 0.092-0.12 vs 0.137 ms): pick what is cheaper for this
+    // tracer count -- in effect 1 per wave only for <= 4 tracers.
+    const int nt = lay->nt;
+    int tw = (0.7*((nt + 3)/4) < 1.0*((nt + 7)/8)) ? 1 : 2;
+    if (const char* e = std::getenv("CEDR_HIP_MICRO_TW")) tw = std::atoi(e) == 1 ? 1 : 2;
+    const int TTm = kNW*tw;
     const size_t ldsm = sizeof(double)*(meta_doubles(st) + 3*mn + kCellRho*kWave +
                                         static_cast<size_t>(TTm)*pitch) +
       (in_rows ? sizeof(double*)*static_cast<size_t>(lay->l2rndps + lay->nt) : 0);
     if (ldsm > 160*1024) return static_cast<int>(hipErrorInvalidValue);
-    const dim3 gridm(st->ntiles, chunk_split(st->ntiles, (lay->nt + TTm - 1)/TTm, kSplitDown));
-    if (in_rows) {
-      int e = set_lds_limit(qlt_down_micro_kernel<TW, true>, ldsm);
+    const dim3 gridm(st->ntiles, chunk_split(st->ntiles, (nt + TTm - 1)/TTm, kSplitDown));
+    auto go = [&] (auto kernel) -> int {
+      int e = set_lds_limit(kernel, ldsm);
       if (e) return e;
-      hipLaunchKernelGGL((qlt_down_micro_kernel<TW, true>), gridm, dim3(kBlock), ldsm, stream,
+      hipLaunchKernelGGL(kernel, gridm, dim3(kBlock), ldsm, stream,
                          *lay, *st, l2r, r2l, in_rows, out_rows, nrow, pitch);
-    } else {
-      int e = set_lds_limit(qlt_down_micro_kernel<TW, false>, ldsm);
-      if (e) return e;
-      hipLaunchKernelGGL((qlt_down_micro_kernel<TW, false>), gridm, dim3(kBlock), ldsm, stream,
-                         *lay, *st, l2r, r2l, in_rows, out_rows, nrow, pitch);
-    }
+      return 0;
+    };
+    int e;
+    if (tw == 1) e = in_rows ? go(qlt_down_micro_kernel<1, true>) : go(qlt_down_micro_kernel<1, false>);
+    else e = in_rows ? go(qlt_down_micro_kernel<2, true>) : go(qlt_down_micro_kernel<2, false>);
+    if (e) return e;
     return launch_status();
   }
   const size_t lds = sizeof(double)*(meta_doubles(st) + 3*mn + static_cast<size_t>(kDownTT)*pitch);
