@@ -230,10 +230,12 @@ void QLTHip::finish_setup () {
     o.trcr2br2l = d.trcr2br2l.data();
   }
   if ( ! d.inited) {
-    size_t l2r_sz, r2l_sz;
-    get_buffers_sizes(l2r_sz, r2l_sz);
-    d.l2r_own.alloc_zero(l2r_sz);
-    d.r2l_own.alloc_zero(r2l_sz);
+    // Own allocation: only what this build's layout touches (fields x stride). That is about
+    // half of the reference's figure, which get_buffers_sizes reports for callers who bring
+    // their own memory: internal tree nodes other than tile outputs never reach HBM here.
+    const size_t stride = static_cast<size_t>(eng_->stride());
+    d.l2r_own.alloc_zero(md_.prob2bl2r[MetaData::nprobtypes]*stride);
+    d.r2l_own.alloc_zero(md_.prob2br2l[MetaData::nprobtypes]*stride);
     d.l2r = d.l2r_own.data();
     d.r2l = d.r2l_own.data();
     d.inited = true;
