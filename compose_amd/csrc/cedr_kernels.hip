@@ -17,6 +17,9 @@
 
 namespace {
 
+#ifndef CEDR_XCD_REMAP
+# define CEDR_XCD_REMAP 1
+#endif
 constexpr int kBlock = 256;          // 4 wavefronts
 constexpr int kWave = 64;
 using namespace cedr_dev;
@@ -40,6 +43,28 @@ __device__ __forceinline__ void stage_tile_meta (const cedr_hip_stage& st, const
   for (int j = threadIdx.x; j < tile.nint; j += kBlock) kidsL[j] = kp[j];
   const int32_t* __restrict__ lp = st.lvlptr + tile.lvl_off;
   for (int j = threadIdx.x; j <= tile.nlvl; j += kBlock) lvlL[j] = lp[j];
+}
+
+// Workgroups are dealt round-robin to the 8 XCDs (blockIdx.x % 8), each with its own L2.
+// Consecutive tiles share the cache lines in which their row segments meet (a tile's
+// ~1.5 KB segment is not line aligned), so every XCD gets a CONTIGUOUS range of tiles:
+// the grid has 8*ceil(n/8) workgroups and workgroup b takes tile (b % 8)*ceil(n/8) + b/8
+// (the up to 7 workgroups that fall past the last tile exit at once).
+__device__ __forceinline__ int xcd_tile (const int ntiles) {
+#if CEDR_XCD_REMAP
+  const int per = gridDim.x >> 3;
+  const int t = (blockIdx.x & 7)*per + (blockIdx.x >> 3);
+  return t < ntiles ? t : -1;
+#else
+  return blockIdx.x;
+#endif
+}
+inline unsigned xcd_grid (const int ntiles) {
+#if CEDR_XCD_REMAP
+  return 8u*static_cast<unsigned>((ntiles + 7)/8);
+#else
+  return static_cast<unsigned>(ntiles);
+#endif
 }
 
 template <int N> struct Log2 { enum { value = 1 + Log2<N/2>::value }; };
@@ -430,7 +455,9 @@ void tree_up_micro_kernel (const cedr_hip_stage st, const int nfields,
   static_assert(FT == 8*kNW || FT == 4*kNW || FT == 2*kNW,
                 "the prefetch wait macros are written for 2, 4 or 8 rows per wave");
   extern __shared__ double lds[];
-  const cedr_hip_tile tile = st.tiles[blockIdx.x];
+  const int tix = xcd_tile(st.ntiles);
+  if (tix < 0) return;
+  const cedr_hip_tile tile = st.tiles[tix];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & (kWave - 1);
   uint32_t* const kidsL = reinterpret_cast<uint32_t*>(lds);
   int32_t* const lvlL = reinterpret_cast<int32_t*>(kidsL + st.max_nint);
@@ -649,7 +676,9 @@ void qlt_down_micro_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st
                             double* const* __restrict__ out_rows, const int nrow, const int pitch) {
   constexpr int TT = kNW*TW;  // tracers per chunk: TW per wave for the register part
   extern __shared__ double lds[];
-  const cedr_hip_tile tile = st.tiles[blockIdx.x];
+  const int tix = xcd_tile(st.ntiles);
+  if (tix < 0) return;
+  const cedr_hip_tile tile = st.tiles[tix];
   const int MN = st.max_nodes;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & (kWave - 1);
   uint32_t* const kidsL = reinterpret_cast<uint32_t*>(lds);
@@ -1394,17 +1423,18 @@ int cedr_hip_tree_up_rows (const cedr_hip_stage* st, int32_t nfields, const uint
     sizeof(int32_t)*static_cast<size_t>(nfields + 2 + kWave);  // + op table, + output node ids
   if (lds > 160*1024) return static_cast<int>(hipErrorInvalidValue);
   const dim3 grid(st->ntiles, chunk_split(st->ntiles, (nfields + kUpFT - 1)/kUpFT, kSplitUp));
+  const dim3 gridx(xcd_grid(st->ntiles), grid.y);  // micro kernels: XCD-contiguous tile ranges
   if (st->micro && in_rows) {
     if (st->max_nleaf > kWave) return static_cast<int>(hipErrorInvalidValue);
     int e = set_lds_limit(tree_up_micro_kernel<kUpFT, true>, lds);
     if (e) return e;
-    hipLaunchKernelGGL((tree_up_micro_kernel<kUpFT, true>), grid, dim3(kBlock), lds, stream,
+    hipLaunchKernelGGL((tree_up_micro_kernel<kUpFT, true>), gridx, dim3(kBlock), lds, stream,
                        *st, nfields, op, stride, data, in_rows, nrow, zero_init, pitch);
   } else if (st->micro) {
     if (st->max_nleaf > kWave) return static_cast<int>(hipErrorInvalidValue);
     int e = set_lds_limit(tree_up_micro_kernel<kUpFT, false>, lds);
     if (e) return e;
-    hipLaunchKernelGGL((tree_up_micro_kernel<kUpFT, false>), grid, dim3(kBlock), lds, stream,
+    hipLaunchKernelGGL((tree_up_micro_kernel<kUpFT, false>), gridx, dim3(kBlock), lds, stream,
                        *st, nfields, op, stride, data, in_rows, nrow, zero_init, pitch);
   } else if (st->max_nleaf <= 128) {
     int e = set_lds_limit(tree_up_kernel<kUpFT, 2>, lds);
@@ -1449,7 +1479,7 @@ int cedr_hip_qlt_down_rows (const cedr_hip_qlt_layout* lay, const cedr_hip_stage
                                         static_cast<size_t>(TTm)*pitch) +
       (in_rows ? sizeof(double*)*static_cast<size_t>(lay->l2rndps + lay->nt) : 0);
     if (ldsm > 160*1024) return static_cast<int>(hipErrorInvalidValue);
-    const dim3 gridm(st->ntiles, chunk_split(st->ntiles, (nt + TTm - 1)/TTm, kSplitDown));
+    const dim3 gridm(xcd_grid(st->ntiles), chunk_split(st->ntiles, (nt + TTm - 1)/TTm, kSplitDown));
     auto go = [&] (auto kernel) -> int {
       int e = set_lds_limit(kernel, ldsm);
       if (e) return e;
