@@ -30,4 +30,9 @@ with open(dst, "w", newline="") as f:
     for (name, grid, wg, vgpr, lds), v in rows:
         gx = int(grid.split("x")[0]) // wg
         w.writerow([name, grid, gx, vgpr, lds, len(v), sum(v), "%.1f" % (sum(v) / len(v)), min(v), max(v)])
+try:
+    for (name, grid, wg, vgpr, lds), v in rows:
+        gx = int(grid.split("x")[0]) // wg
         print("%-28s grid %-18s wgs_x %-6d calls %4d avg %10.1f us" % (name, grid, gx, len(v), sum(v) / len(v) / 1e3))
+except BrokenPipeError:  # `| head`
+    pass
