@@ -715,12 +715,17 @@ void qlt_down_micro_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st
     }
     if (ROWS) {
       const double* const* rows = staged ? inL : in_rows;
+      // (__restrict__ locals: the rows are never written by this kernel's stores, which lets
+      // the compiler schedule these loads as freely as those from l2r in the packed variant)
+      const double* __restrict__ const r0 = rows[field] + tile.in0;
       if (sp) {
-        load_roles_edge(rows[field] + tile.in0, ro, ushift, buf[0][0], buf[1][0], buf[2][0]);
-        load_roles_edge(rows[field + 1] + tile.in0, ro, ushift, buf[0][1], buf[1][1], buf[2][1]);
-        load_roles_edge(rows[field + 2] + tile.in0, ro, ushift, buf[0][2], buf[1][2], buf[2][2]);
+        const double* __restrict__ const r1 = rows[field + 1] + tile.in0;
+        const double* __restrict__ const r2 = rows[field + 2] + tile.in0;
+        load_roles_edge(r0, ro, ushift, buf[0][0], buf[1][0], buf[2][0]);
+        load_roles_edge(r1, ro, ushift, buf[0][1], buf[1][1], buf[2][1]);
+        load_roles_edge(r2, ro, ushift, buf[0][2], buf[1][2], buf[2][2]);
       } else {
-        load_roles_edge(rows[field] + tile.in0, ro, ushift, buf[0][1], buf[1][1], buf[2][1]);
+        load_roles_edge(r0, ro, ushift, buf[0][1], buf[1][1], buf[2][1]);
         buf[0][0] = buf[1][0] = buf[2][0] = 0.0;
         buf[0][2] = buf[1][2] = buf[2][2] = 0.0;
       }
@@ -919,7 +924,10 @@ void qlt_down_micro_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st
       else
         micro_solves<false>(m.shape, any2, any3, ptw, rr, ku, kv, kp, kt, cur[s], T, RR, Xr, qlw, qhw, prefer,
                             Xu, Xv, Xp);
-      store_roles((ROWS ? outL[biw] : r2l + static_cast<size_t>(rbw)*S) + tile.in0, ro, Xu, Xv, Xp);
+      {  // (a cell's result is never read back by this kernel, also when Qm_out is Qm itself)
+        double* __restrict__ const orow = (ROWS ? outL[biw] : r2l + static_cast<size_t>(rbw)*S) + tile.in0;
+        store_roles(orow, ro, Xu, Xv, Xp);
+      }
       if (t_onlyw) {
         double* __restrict__ dst = r2l + static_cast<size_t>(rbw)*S + tile.in0 + m.start;
         double* __restrict__ l0p = l2r + static_cast<size_t>(L.bidx_l2r[biw])*S + tile.in0 + m.start;
