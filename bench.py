@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--ncells", type=int, default=1500000)
     ap.add_argument("--ntracers", type=int, default=40)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-cells", type=int, default=375000,
+    ap.add_argument("--cpu-cells", type=int, default=750000,
                     help="cells of the bounded CPU-baseline sample (same tracer count)")
     ap.add_argument("--check", action="store_true", help="verify properties of the results")
     ap.add_argument("--serial", action="store_true",
@@ -84,7 +84,7 @@ def gen_inputs(torch, n, nt, seed, device):
     return rhom, Qm.contiguous(), Qm_min.contiguous(), Qm_max.contiguous(), Qm_prev.contiguous()
 
 
-def cpu_baseline(ncells, nt, nrep_qlt=2, nrep_caas=4):
+def cpu_baseline(ncells, nt, nrep_qlt=6, nrep_caas=10):
     """The oracle (CPU port of the reference algorithm) timed on this host: the
     reported CPU baseline, never the thing measured as `value`."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
