@@ -6,11 +6,14 @@ One "step" = one QLT::run() plus one CAAS::run() over the same synthetic
 resident in HBM before the timed region. value = cell-tracer
 updates by both algorithms per second = 2*ncells*ntracers / time per step.
 
-N GPUs: `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`;
-the global problem is sharded contiguously over ranks (strong scaling). The data
+N GPUs: `python bench.py --gpus N ...` starts its own N rank processes (fresh children,
+spawned before anything touches a GPU; rank 0's JSON line is relayed), and
+`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` works too.
+The global problem is sharded contiguously over ranks (strong scaling). The data
 path uses the library's own RCCL communicator (one all-gather per QLT run, one
-all-reduce per CAAS run); torch.distributed (gloo) is only the control plane
-(unique-id broadcast, barriers, max over ranks).
+all-reduce per CAAS run, strictly ordered on ONE stream when N > 1);
+torch.distributed (gloo) is only the control plane (unique-id broadcast, barriers,
+max over ranks). A transport that fails ends the run with a non-zero exit code.
 """
 import argparse
 import json
@@ -41,11 +44,18 @@ def parse():
     ap.add_argument("--cpu-cells", type=int, default=750000,
                     help="cells of the bounded CPU-baseline sample (same tracer count)")
     ap.add_argument("--check", action="store_true", help="verify properties of the results")
-    ap.add_argument("--serial", action="store_true",
-                    help="run QLT and CAAS back to back on one stream instead of on two concurrent streams")
+    ap.add_argument("--overlap", action="store_true",
+                    help="N = 1 only: QLT and CAAS on two concurrent streams instead of back to back on one "
+                         "(measured: within 2 %% of the one-stream step). With N > 1 the two CDRs share one "
+                         "communicator and one stream, so their collectives are strictly ordered.")
+    ap.add_argument("--serial", action="store_true", help="(default now; kept for older command lines)")
     ap.add_argument("--comm", choices=["rccl", "gloo"], default="rccl",
                     help="data-path transport for N > 1: the library's RCCL communicator (default) or, "
                          "for rehearsals on one GPU, host-staged torch.distributed/gloo callbacks")
+    ap.add_argument("--allow-host-fallback", action="store_true",
+                    help="launcher mode only: if the RCCL run fails, start a FRESH set of rank processes "
+                         "with --comm gloo (host-staged) and say so in the JSON line; without this flag a "
+                         "failed transport is a failed run")
     ap.add_argument("--caas-bfb", type=int, default=0, metavar="ACCUM",
                     help="CAAS with the BFB tree all-reduce as its UserAllReducer (the production pairing): "
                          "ACCUM cells per reducer leaf (n_accum_in_place), e.g. 4; 0 = CAAS's own all-reduce")
@@ -123,8 +133,53 @@ def cpu_baseline(ncells, nt, nrep_qlt=6, nrep_caas=10):
     return res, nthr
 
 
+def spawn_ranks(a):
+    """`python bench.py --gpus N` typed as is: start N fresh rank processes (one per GPU) and
+    relay rank 0's JSON line. Runs before this process has imported torch or touched a GPU;
+    nothing is ever exec'ed from a process that has."""
+    import signal
+    import socket
+    import subprocess
+
+    def run_once(extra):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        procs = []
+        for r in range(a.gpus):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus),
+                       LOCAL_WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+            # rank 0 writes the JSON line to our stdout; the other ranks' stdout goes to stderr
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + extra,
+                                          env=env, stdout=None if r == 0 else sys.stderr))
+        rc, deadline = 0, None
+        while any(p.poll() is None for p in procs):
+            for p in procs:
+                if p.poll() not in (None, 0) and rc == 0:
+                    rc = p.returncode
+                    deadline = time.monotonic() + 20  # peers may sit in a collective: do not wait for ever
+            if deadline is not None and time.monotonic() > deadline:
+                for p in procs:
+                    if p.poll() is None:
+                        p.send_signal(signal.SIGKILL)  # exactly the children started above
+            time.sleep(0.2)
+        for p in procs:
+            if p.returncode != 0 and rc == 0:
+                rc = p.returncode
+        return rc
+
+    rc = run_once([])
+    if rc != 0 and a.allow_host_fallback and a.comm == "rccl":
+        print("bench.py: the RCCL run failed (exit %d); --allow-host-fallback: fresh ranks with --comm gloo" % rc,
+              file=sys.stderr)
+        rc = run_once(["--comm", "gloo"])
+    sys.exit(rc)
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "RANK" not in os.environ:
+        spawn_ranks(a)  # does not return
     import torch
     import torch.distributed as dist
     import compose_amd as ca
@@ -133,14 +188,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d`"
-                             % (a.gpus, a.gpus))
         raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, a.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback)")
     if a.same_gpu:
         local_rank = 0
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit("rank %d: no GPU %d on this node (%d visible); --gpus must not exceed the GPU count"
+                         % (rank, local_rank, torch.cuda.device_count()))
+    if a.overlap and world > 1:
+        raise SystemExit("--overlap is for N = 1: concurrent collectives of two communicators on one "
+                         "device have no forward-progress guarantee")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     torch.zeros(1, device=device)  # initialise the HIP context before the library is used
@@ -189,18 +247,16 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo", rank=rank, world_size=world)
-        transport = a.comm
-        qlt = caas = None
         if a.comm == "rccl":
-            # One communicator per CDR: their collectives run on different streams.
-            uid = [[ca.Parallel.rccl_unique_id(), ca.Parallel.rccl_unique_id()] if rank == 0 else None]
+            # ONE communicator for both CDRs and ONE stream: the all-gather of QLT::run and the
+            # all-reduce of CAAS::run are enqueued in the same order on every rank.
+            uid = [ca.Parallel.rccl_unique_id() if rank == 0 else None]
             dist.broadcast_object_list(uid, src=0)
             err = None
             try:
-                par = ca.Parallel.rccl(uid[0][0], rank, world)
-                par2 = ca.Parallel.rccl(uid[0][1], rank, world)
+                par = par2 = ca.Parallel.rccl(uid[0], rank, world)
                 qlt, caas = make_cdrs(par, par2)
-                # one untimed exchange through each communicator before anything is measured
+                # one untimed exchange through the communicator before anything is measured
                 z = torch.zeros((nt, qlt.nlclcells()), dtype=torch.float64, device=device)
                 o = torch.ones(qlt.nlclcells(), dtype=torch.float64, device=device)
                 qlt.set_rhom(o); qlt.set_Qm(z, z, z, z); qlt.run()
@@ -212,22 +268,21 @@ def main():
             errs = [None] * world
             dist.all_gather_object(errs, err)
             if any(errs):
-                # The kernels are the product; the transport is replaceable. Keep measuring,
-                # with the collectives staged through the host, and say so in the JSON line.
-                first = next(e for e in errs if e)
+                # A transport that does not work is a failed run: never report host-staged
+                # numbers as multi-GPU results (a fresh `--comm gloo` run is the caller's choice).
                 if rank == 0:
-                    print("bench.py: RCCL transport unusable (%s); falling back to host-staged gloo" % first,
-                          file=sys.stderr)
-                transport = "gloo-host-staged (RCCL failed: %s)" % first[:200]
-                qlt = caas = None
-        if qlt is None:
+                    print("bench.py: RCCL transport failed: %s" % next(e for e in errs if e), file=sys.stderr)
+                dist.destroy_process_group()
+                sys.exit(3)
+            transport = "rccl: one communicator of %d ranks, one stream, collectives in program order" % world
+        else:
             par = par2 = host_staged()
             qlt, caas = make_cdrs(par, par2)
+            transport = "gloo-host-staged (rehearsal transport, not RCCL)"
     else:
         par = par2 = ca.Parallel.self_()
         qlt, caas = make_cdrs(par, par2)
     n = qlt.nlclcells()
-    host_comm = world > 1 and not transport.startswith("rccl")
 
     rhom, Qm, Qm_min, Qm_max, Qm_prev = gen_inputs(torch, n, nt, 0x5EED0000 + 1000 * 2 + rank, device)
     qlt.set_rhom(rhom)
@@ -236,10 +291,9 @@ def main():
     caas.set_Qm(Qm, Qm_min, Qm_max, Qm_prev)
     caas.set_Qm_source(Qm)  # every run() reads the pristine Qm: identical work each step
     torch.cuda.synchronize()
-    # QLT and CAAS are independent CDRs: each gets its own HIP stream so that the
-    # latency-bound upper stages / collectives of one overlap the streaming kernels of the other.
+    # Default: QLT::run then CAAS::run on one stream. --overlap (N = 1): each CDR on its own stream.
     streams = None
-    if not a.serial and not host_comm:  # host-staged callbacks are not stream ordered
+    if a.overlap and world == 1:
         streams = (torch.cuda.Stream(device=device), torch.cuda.Stream(device=device))
         qlt.set_stream(streams[0].cuda_stream)
         caas.set_stream(streams[1].cuda_stream)
@@ -388,6 +442,9 @@ def main():
         caas.get_Qm(out)
         torch.cuda.synchronize()
         ok = ok and bool(((out >= Qm_min) & (out <= Qm_max)).all())
+        if world > 1:  # every rank's verdict
+            okt = torch.tensor([1 if ok else 0]); dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+            ok = bool(int(okt[0]))
 
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
@@ -412,7 +469,8 @@ def main():
                                    "contiguous %d-way sharding" % (" on two concurrent streams" if streams else "",
                                                                    ncells, nt, world),
                        "ncells": ncells, "ntracers": nt, "cells_per_gpu": n,
-                       "transport": transport,
+                       "transport": transport, "rccl_nranks": world if (world > 1 and a.comm == "rccl") else 0,
+                       "streams": 2 if streams else 1,
                        "caas_reducer": ("bfb_tree_allreduce, %d cells per leaf" % a.caas_bfb) if a.caas_bfb
                        else "own all-reduce"},
             "qlt": {"ms_per_run": 1e3 * t_qlt, "updates_per_s": ncells * nt / t_qlt},
@@ -425,6 +483,8 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if ok is False:
+        sys.exit(4)  # --check failed: the JSON line says check_ok false, and the run fails
 
 
 if __name__ == "__main__":

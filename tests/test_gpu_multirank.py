@@ -42,30 +42,45 @@ def test_rccl_single_rank(gpu, oracle):
     assert np.abs(got - want).max() / np.abs(want).max() <= 1e-13
 
 
+def _bench(args, timeout=600):
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True,
+                         timeout=timeout, cwd=ROOT)
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    return res, (json.loads(lines[-1]) if lines else None)
+
+
+SMALL = ["--steps", "2", "--warmup", "1", "--ncells", "30000", "--ntracers", "6", "--same-gpu", "--check",
+         "--no-cpu-baseline"]
+
+
 @pytest.mark.parametrize("nranks", [2, 3])
-def test_bench_multiprocess_same_gpu(gpu, nranks):
-    port = 29500 + nranks
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nranks),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
-           "--gpus", str(nranks), "--steps", "2", "--warmup", "1", "--ncells", "30000", "--ntracers", "6",
-           "--comm", "gloo", "--same-gpu", "--check", "--no-cpu-baseline"]
-    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+def test_bench_self_spawned_ranks_same_gpu(gpu, nranks):
+    """`python bench.py --gpus N` exactly as typed: bench.py starts its own rank processes."""
+    res, d = _bench(["--gpus", str(nranks), "--comm", "gloo"] + SMALL)
     assert res.returncode == 0, res.stdout[-1500:] + res.stderr[-1500:]
-    line = [l for l in res.stdout.splitlines() if l.startswith("{")][-1]
-    d = json.loads(line)
     assert d["n_gpus"] == nranks and d["check_ok"] is True and d["scaling"] == "strong"
+    assert d["config"]["rccl_nranks"] == 0 and d["config"]["transport"].startswith("gloo-host-staged")
 
 
-def test_bench_rccl_failure_falls_back_to_host_staged(gpu):
-    """Two ranks on ONE GPU make ncclCommInitRank fail (duplicate device): bench.py must
-    notice on every rank, switch the collectives to the host-staged transport, still
-    produce correct results, and say which transport it measured."""
+def test_bench_under_torch_distributed_run(gpu):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-           "--master-addr", "127.0.0.1", "--master-port", "29507", os.path.join(ROOT, "bench.py"),
-           "--gpus", "2", "--steps", "2", "--warmup", "1", "--ncells", "30000", "--ntracers", "6",
-           "--comm", "rccl", "--same-gpu", "--check", "--no-cpu-baseline"]
+           "--master-addr", "127.0.0.1", "--master-port", "29502", os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--comm", "gloo"] + SMALL
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert res.returncode == 0, res.stdout[-1500:] + res.stderr[-1500:]
     d = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
-    assert d["check_ok"] is True
-    assert d["config"]["transport"].startswith("gloo-host-staged (RCCL failed")
+    assert d["n_gpus"] == 2 and d["check_ok"] is True
+
+
+def test_bench_rccl_failure_is_a_failed_run(gpu):
+    """Two ranks on ONE GPU make ncclCommInitRank fail (duplicate device): every rank must
+    notice, no JSON line with a value may appear, and the exit code must be non-zero. Only with
+    --allow-host-fallback does the launcher start FRESH ranks on the host-staged transport,
+    and the line then says so."""
+    res, d = _bench(["--gpus", "2", "--comm", "rccl"] + SMALL)
+    assert res.returncode != 0 and d is None, res.stdout[-1500:]
+    assert "RCCL transport failed" in res.stderr
+    res, d = _bench(["--gpus", "2", "--comm", "rccl", "--allow-host-fallback"] + SMALL)
+    assert res.returncode == 0, res.stdout[-1500:] + res.stderr[-1500:]
+    assert d["check_ok"] is True and d["config"]["rccl_nranks"] == 0
+    assert d["config"]["transport"].startswith("gloo-host-staged")
