@@ -150,6 +150,9 @@ _SIGS = {
     "cedr_hip_profile_stop": (C.c_int, []),
     "cedr_hip_profile_get": (C.c_int, [C.c_int, _ip, C.POINTER(C.c_int64), C.POINTER(C.c_float)]),
     "cedr_hip_profile_name": (C.c_char_p, [C.c_int]),
+    "cedr_local_solve": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, C.c_double, _dp, _dp, _dp, _dp]),
+    "cedr_hip_local_batch": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p]),
 }
 
 _LIB = None
@@ -239,6 +242,37 @@ class DeviceArray:
                 lib().cedr_free(self.ptr)
         except Exception:
             pass
+
+
+LOCAL_BC_QP, LOCAL_BC_QP_2D, LOCAL_CAAS, LOCAL_NONNEG_LS, LOCAL_NONNEG_CAAS = range(5)
+
+
+def local_solve(kind, w, a, b, xlo, xhi, y, clip=True, early_exit_on_tol=True, max_its=100):
+    """cedr::local::* evaluated on the HOST by libcedr_hip.so (cedr_local.hpp; reference
+    cedr/cedr_local.hpp:24-60). Returns (info, x)."""
+    arrs = [np.ascontiguousarray(v, np.float64) for v in (w, a, xlo, xhi, y)]
+    n = len(arrs[1])
+    x = np.zeros(n)
+    flags = (1 if clip else 0) | (2 if early_exit_on_tol else 0)
+    info = lib().cedr_local_solve(kind, n, flags, max_its, arrs[0].ctypes.data_as(_dp), arrs[1].ctypes.data_as(_dp),
+                                  float(b), arrs[2].ctypes.data_as(_dp), arrs[3].ctypes.data_as(_dp),
+                                  arrs[4].ctypes.data_as(_dp), x.ctypes.data_as(_dp))
+    return info, x
+
+
+def local_batch(kind, w, a, b, xlo, xhi, y, clip=True, early_exit_on_tol=True, max_its=100):
+    """The same functions on the GPU, one problem per thread. Arrays are [nprob][n], b is [nprob].
+    Returns (info[nprob], x[nprob][n])."""
+    w, a, xlo, xhi, y = (np.ascontiguousarray(v, np.float64) for v in (w, a, xlo, xhi, y))
+    nprob, n = a.shape
+    rec = np.concatenate([w, a, xlo, xhi, y, np.asarray(b, np.float64).reshape(nprob, 1)], axis=1)
+    din = DeviceArray.from_numpy(rec)
+    dx = DeviceArray(nprob * n)
+    di = DeviceArray(nprob, np.int32)
+    flags = (1 if clip else 0) | (2 if early_exit_on_tol else 0)
+    _chk(lib().cedr_hip_local_batch(kind, nprob, n, flags, max_its, din.ptr, dx.ptr, di.ptr, None), "local_batch")
+    synchronize()
+    return di.numpy(), dx.numpy((nprob, n))
 
 
 class Parallel:

@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "../../include/cedr_hip.h"
+#include "cedr_local.hpp"
 #include "cedr_node_math.hpp"
 
 namespace {
@@ -1334,6 +1335,37 @@ void caas_finish_kernel (const int nt, const int n, double* __restrict__ qm_io,
 }
 
 
+// ---------------------------------------------------------- cedr::local batch
+// One problem per thread through the public cedr::local functions (cedr_local.hpp).
+__device__ __host__ inline int local_dispatch (const int kind, const int n, const int flags, const int max_its,
+                                               const double* w, const double* a, const double b,
+                                               const double* xlo, const double* xhi, const double* y,
+                                               double* x) {
+  namespace cl = cedr::local;
+  switch (kind) {
+  case CEDR_LOCAL_BC_QP: return cl::solve_1eq_bc_qp(n, w, a, b, xlo, xhi, y, x, max_its);
+  case CEDR_LOCAL_BC_QP_2D: return cl::solve_1eq_bc_qp_2d(w, a, b, xlo, xhi, y, x, (flags & 1) != 0, (flags & 2) != 0);
+  case CEDR_LOCAL_CAAS: cl::caas(n, a, b, xlo, xhi, y, x, (flags & 1) != 0); return 0;
+  case CEDR_LOCAL_NONNEG_LS: return cl::solve_1eq_nonneg(n, a, b, y, x, w, cl::Method::least_squares);
+  case CEDR_LOCAL_NONNEG_CAAS: return cl::solve_1eq_nonneg(n, a, b, y, x, w, cl::Method::caas);
+  default: return -3;
+  }
+}
+
+__global__ void local_batch_kernel (const int kind, const int nprob, const int n, const int flags,
+                                    const int max_its, const double* __restrict__ in,
+                                    double* __restrict__ xout, int32_t* __restrict__ info) {
+  const int p = blockIdx.x*blockDim.x + threadIdx.x;
+  if (p >= nprob) return;
+  double v[5][16], x[16];
+  const double* q = in + static_cast<size_t>(p)*(5*n + 1);
+  for (int k = 0; k < 5; ++k)
+    for (int i = 0; i < n; ++i) v[k][i] = q[k*n + i];
+  for (int i = 0; i < n; ++i) x[i] = 0;
+  info[p] = local_dispatch(kind, n, flags, max_its, v[0], v[1], q[5*n], v[2], v[3], v[4], x);
+  for (int i = 0; i < n; ++i) xout[static_cast<size_t>(p)*n + i] = x[i];
+}
+
 // ------------------------------------------------------------ launch profiler
 // Optional HIP-event timing of every layer-K launch, on the stream the kernel
 // is launched on. Off by default; bench.py switches it on for its roofline leg.
@@ -1678,6 +1710,22 @@ int cedr_hip_caas_finish_local (int32_t nt, int32_t n, double* d, const double* 
   const size_t N = n;
   return cedr_hip_caas_finish_local_arrays(nt, n, d + N, d + (1 + static_cast<size_t>(nt))*N,
                                            d + (1 + 2*static_cast<size_t>(nt))*N, recv, stream);
+}
+
+int cedr_local_solve (int kind, int n, int flags, int max_its, const double* w, const double* a, double b,
+                      const double* xlo, const double* xhi, const double* y, double* x) {
+  if (n < 1 || n > 16 || (kind == CEDR_LOCAL_BC_QP_2D && n != 2)) return -3;
+  return local_dispatch(kind, n, flags, max_its, w, a, b, xlo, xhi, y, x);
+}
+
+int cedr_hip_local_batch (int kind, int nprob, int n, int flags, int max_its, const double* in_dev,
+                          double* x_dev, int32_t* info_dev, cedr_stream_t stream) {
+  if (n < 1 || n > 16 || (kind == CEDR_LOCAL_BC_QP_2D && n != 2) || kind < 0 || kind > 4)
+    return static_cast<int>(hipErrorInvalidValue);
+  if (nprob <= 0) return 0;
+  hipLaunchKernelGGL(local_batch_kernel, dim3((nprob + 63)/64), dim3(64), 0, stream, kind, nprob, n, flags,
+                     max_its, in_dev, x_dev, info_dev);
+  return launch_status();
 }
 
 void cedr_hip_profile_start (void) {

@@ -310,6 +310,20 @@ int cedr_bfb_allreduce(void* bfb, const double* send, double* recv, int transpos
  * used inside CAAS::run must use CAAS's stream. */
 int cedr_bfb_set_stream(void* bfb, cedr_stream_t stream);
 
+/* -- cedr::local scalar solvers (reference cedr/cedr_local.hpp:24-60) --------- */
+/* The same `__host__ __device__` functions of compose_amd/csrc/cedr_local.hpp, evaluated on
+ * the HOST (cedr_local_*) or, one problem per GPU thread, on the DEVICE (cedr_hip_local_batch).
+ * kind: 0 solve_1eq_bc_qp, 1 solve_1eq_bc_qp_2d, 2 caas, 3 solve_1eq_nonneg(least_squares),
+ * 4 solve_1eq_nonneg(caas). flags (kinds 1, 2): bit 0 = clip, bit 1 = early_exit_on_tol.
+ * Problem p of a batch: in[p*(5n+1) ..] = w[n], a[n], xlo[n], xhi[n], y[n], b;
+ * x[p*n ..] receives the solution and info[p] the function's return value (0 for caas). */
+enum { CEDR_LOCAL_BC_QP = 0, CEDR_LOCAL_BC_QP_2D = 1, CEDR_LOCAL_CAAS = 2,
+       CEDR_LOCAL_NONNEG_LS = 3, CEDR_LOCAL_NONNEG_CAAS = 4 };
+int cedr_local_solve(int kind, int n, int flags, int max_its, const double* w, const double* a, double b,
+                     const double* xlo, const double* xhi, const double* y, double* x);
+int cedr_hip_local_batch(int kind, int nprob, int n, int flags, int max_its, const double* in_dev,
+                         double* x_dev, int32_t* info_dev, cedr_stream_t stream);
+
 /* -- device memory helpers for hosts without their own HIP bindings ---------- */
 int cedr_device_count(void);
 void* cedr_malloc(size_t bytes);
