@@ -68,6 +68,16 @@ inline unsigned xcd_grid (const int ntiles) {
 #endif
 }
 
+// Diagnostic builds only (wrong results): -DCEDR_DIAG_L2 makes every tile read its cell records from
+// the first 4096 cells of each row, i.e. from cache-resident memory -- the sweep without its HBM reads.
+__device__ __forceinline__ int diag_in0 (const int in0) {
+#ifdef CEDR_DIAG_L2
+  return in0 & 4095;
+#else
+  return in0;
+#endif
+}
+
 template <int N> struct Log2 { enum { value = 1 + Log2<N/2>::value }; };
 template <> struct Log2<1> { enum { value = 0 }; };
 
@@ -732,7 +742,7 @@ void qlt_down_micro_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st
       }
       return;
     }
-    const double* __restrict__ s0 = l2r + static_cast<size_t>(field)*S + tile.in0;
+    const double* __restrict__ s0 = l2r + static_cast<size_t>(field)*S + diag_in0(tile.in0);
     if (sp) {
       load_roles(s0, ro, buf[0][0], buf[1][0], buf[2][0]);
       load_roles(s0 + S, ro, buf[0][1], buf[1][1], buf[2][1]);
@@ -943,6 +953,239 @@ void qlt_down_micro_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st
   if (lane == 0)
     for (int i = 0; i < 6; ++i) atomicAdd(&g_stamps[wave*8 + i], acc[i]);
 #endif
+}
+
+// ---------------------------------------------------------------------------
+// Root -> leaves over micro tiles when EVERY tracer is shape preserving (E3SM's
+// case: all cst). Same tile walk and the same node problems as
+// qlt_down_micro_kernel; what differs follows from what was measured on that kernel
+// (profiles/r02_down_experiments.md):
+//  * With the cell records read from cache instead of HBM the sweep is as slow: it is
+//    bound by the node problems' instruction issue (a wave alone issues one fp64
+//    instruction per ~6-8 cycles; the SIMD can take one per 4), not by memory. So the
+//    kernel is built for OCCUPANCY: one tracer per wave, no prefetch registers, the
+//    problem type fixed at compile time (half the code, ~115 VGPRs: 4 waves per SIMD).
+//    A register prefetch of the next chunk (inline asm, as tree_up_micro_kernel has) cost
+//    more in registers than the memory latency it hid: 0.64 vs 0.56 ms.
+//  * The chain of dependent tree levels per chunk sets how well workgroups overlap, so
+//    the sums of the LDS levels are formed by the wave that owns the tracer, without
+//    workgroup barriers (a wave's LDS accesses execute in program order), and the plan
+//    cuts first-stage tiles to two LDS levels.
+//  * The densities of a lane's micro-subtree are derived by all four waves, one role each.
+#ifndef CEDR_DOWN_SP_WAVES2
+# define CEDR_DOWN_SP_WAVES2 3  // waves per SIMD the 2-tracers-per-wave build is compiled for
+#endif
+#ifndef CEDR_DOWN_SP_WAVES1
+# define CEDR_DOWN_SP_WAVES1 5  // ... and the 1-tracer-per-wave build
+#endif
+
+// LDS accesses of ONE wave execute in program order, so data a lane wrote can be read by another
+// lane of the same wave without a workgroup barrier; this only keeps the COMPILER from moving LDS
+// accesses across the point (no instruction is generated).
+__device__ __forceinline__ void wave_lds_order () {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int TW, bool ROWS>
+__global__ __launch_bounds__(kBlock, TW == 1 ? CEDR_DOWN_SP_WAVES1 : CEDR_DOWN_SP_WAVES2)
+void qlt_down_sp_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st,
+                         double* __restrict__ l2r, double* __restrict__ r2l,
+                         const double* const* __restrict__ in_rows,
+                         double* const* __restrict__ out_rows, const int nrow, const int pitch) {
+  constexpr int TT = kNW*TW;
+  extern __shared__ double lds[];
+  const int tix = xcd_tile(st.ntiles);
+  if (tix < 0) return;
+  const cedr_hip_tile tile = st.tiles[tix];
+  const int MN = st.max_nodes;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & (kWave - 1);
+  uint32_t* const kidsL = reinterpret_cast<uint32_t*>(lds);
+  int32_t* const lvlL = reinterpret_cast<int32_t*>(kidsL + st.max_nint);
+  double* const rho = lds + (st.max_nint + 1);
+  double* const rw = rho + MN;
+  double* const rq = rw + MN;
+  double* const cellrho = rq + MN;            // [kCellRho][kWave]
+  double* const recs = cellrho + kCellRho*kWave;
+  // after the records: row tables (ROWS), then the tracers' l2r field / r2l row and the outputs' node ids
+  const double** const inL = reinterpret_cast<const double**>(recs + static_cast<size_t>(TT)*pitch);
+  double** const outL = reinterpret_cast<double**>(recs + static_cast<size_t>(TT)*pitch) + (ROWS ? L.l2rndps : 0);
+  int32_t* const fldL = reinterpret_cast<int32_t*>(outL + (ROWS ? L.nt : 0));
+  int32_t* const r2lL = fldL + L.nt;
+  int32_t* const onodeL = r2lL + L.nt;        // [<= kWave]
+  const int nleaf = tile.nleaf;
+  const int64_t S = L.stride;
+  const bool prefer = L.prefer_mass_con != 0;
+  const int nt = L.nt;
+  const int nchunks = (nt + TT - 1)/TT;
+  const Micro m = get_micro(st, tile, lane);
+  const Roles ro = get_roles(m);
+  const bool any2 = __ballot(m.shape == 2) != 0, any3 = __ballot(m.shape == 3) != 0;
+  const int ushift = (ROWS && tile.in0 + ro.oUV + 1 > nrow - 1) ? 1 : 0;
+  const int tt = threadIdx.x & (TT - 1);      // tracer of this thread in the LDS phases
+
+  // The records {lo, orig, hi} of this lane's cells for this wave's tracers of chunk c, and the
+  // assigned mass of tile output 'lane' (a micro tile has <= 64 outputs).
+  // 'staged': the LDS copies of the tables are visible (not yet for the first chunk).
+  auto load = [&] (const int c, double (&cur)[TW][3][3], double (&X)[TW], const bool staged) {
+#pragma unroll
+    for (int s = 0; s < TW; ++s) {
+      int bi = c*TT + wave + kNW*s;
+      if (bi > nt - 1) bi = nt - 1;  // past the last tracer: re-read it (discarded)
+      const int field = staged ? fldL[bi] : L.bidx_l2r[bi];
+#pragma unroll
+      for (int f = 0; f < 3; ++f) {
+        const double* __restrict__ const row =
+          (ROWS ? (staged ? inL[field + f] : in_rows[field + f]) : l2r + static_cast<size_t>(field + f)*S) +
+          diag_in0(tile.in0);
+        if (ROWS) load_roles_edge(row, ro, ushift, cur[s][0][f], cur[s][1][f], cur[s][2][f]);
+        else load_roles(row, ro, cur[s][0][f], cur[s][1][f], cur[s][2][f]);
+      }
+      const int rb = staged ? r2lL[bi] : L.bidx_r2l[bi];
+      X[s] = r2l[static_cast<size_t>(rb)*S + tile.out + (lane < tile.nout ? lane : tile.nout - 1)];
+    }
+  };
+
+  double cur[TW][3][3], Xout[TW];
+  load(blockIdx.y, cur, Xout, false);
+  if (ROWS) {
+    for (int i = threadIdx.x; i < L.l2rndps; i += kBlock) inL[i] = in_rows[i];
+    for (int i = threadIdx.x; i < nt; i += kBlock) outL[i] = out_rows[i];
+  }
+  for (int i = threadIdx.x; i < nt; i += kBlock) { fldL[i] = L.bidx_l2r[i]; r2lL[i] = L.bidx_r2l[i]; }
+  for (int i = threadIdx.x; i < tile.nout; i += kBlock) onodeL[i] = st.outs[tile.outs_off + i];
+
+  // Densities: wave r derives role r of every micro-subtree (u, v, p, inner pair t):
+  // two divisions per thread. Wave 3 also has the micro-subtree's root density.
+  {
+    double rh[3];
+    if (ROWS) load_roles_edge(in_rows[0] + tile.in0, ro, ushift, rh[0], rh[1], rh[2]);
+    else load_roles(l2r + tile.in0, ro, rh[0], rh[1], rh[2]);
+    if (m.shape < 0) rh[0] = 1.0;
+    if (m.shape < 1) rh[1] = 1.0;
+    if (m.shape < 2) rh[2] = 1.0;
+    const double t = rh[0] + rh[1];
+    const double mine = wave == 0 ? rh[0] : (wave == 1 ? rh[1] : (wave == 2 ? rh[2] : t));
+    const double w = 1.0/mine;
+    cellrho[(3*wave    )*kWave + lane] = mine;
+    cellrho[(3*wave + 1)*kWave + lane] = w;
+    cellrho[(3*wave + 2)*kWave + lane] = 1.0/w;
+    // (a,b)+c and a+(b,c) are the same sum: fp addition commutes
+    if (wave == 3 && lane < nleaf) rho[lane] = m.shape <= 0 ? rh[0] : (m.shape == 1 ? t : t + rh[2]);
+  }
+  stage_tile_meta(st, tile, kidsL, lvlL);
+  __syncthreads();
+  for (int lv = 0; lv < tile.nlvl; ++lv) {
+    const int a = lvlL[lv], b = lvlL[lv+1];
+    for (int j = a + threadIdx.x; j < b; j += kBlock) {
+      const uint32_t kk = kidsL[j];
+      rho[nleaf + j] = rho[kk & 0xffff] + rho[kk >> 16];
+    }
+    __syncthreads();
+  }
+  for (int i = threadIdx.x; i < nleaf + tile.nint; i += kBlock) {
+    const double w = 1.0/rho[i];
+    rw[i] = w;
+    rq[i] = 1.0/w;
+  }
+  double* const R = recs + tt*pitch;          // this thread's record row in the LDS phases
+
+  for (int c = blockIdx.y; c < nchunks; c += gridDim.y) {
+    if (c != static_cast<int>(blockIdx.y)) load(c, cur, Xout, true);
+
+    // ---- this wave's tracers: micro-subtree sums in registers, root records to LDS, the sums
+    // of the LDS tree's nodes above them and the outputs' assigned masses -- all by this wave
+    // alone, so no workgroup barrier separates the levels. (The previous chunk's last reads of
+    // these rows were this wave's own, or lie before that chunk's last barrier.)
+#pragma unroll
+    for (int s = 0; s < TW; ++s) {
+      double* const Rw = recs + (wave + kNW*s)*pitch;
+#pragma unroll
+      for (int f = 0; f < 3; ++f) {
+        const double t = cur[s][0][f] + cur[s][1][f];
+        const double r = m.shape <= 0 ? cur[s][0][f] : (m.shape == 1 ? t : t + cur[s][2][f]);
+        if (lane < nleaf) Rw[4*lane + f] = r;
+      }
+    }
+    for (int lv = 0; lv < tile.nlvl; ++lv) {
+      wave_lds_order();
+      const int a = lvlL[lv], b = lvlL[lv+1];
+#pragma unroll
+      for (int s = 0; s < TW; ++s) {
+        double* const Rw = recs + (wave + kNW*s)*pitch;
+        for (int j = a + lane; j < b; j += kWave) {
+          const uint32_t kk = kidsL[j];
+          const double* K0 = Rw + 4*(kk & 0xffff);
+          const double* K1 = Rw + 4*(kk >> 16);
+          double* me = Rw + 4*(nleaf + j);
+          me[0] = K0[0] + K1[0]; me[2] = K0[2] + K1[2];
+          me[1] = K0[1] + K1[1];
+        }
+      }
+    }
+    wave_lds_order();
+#pragma unroll
+    for (int s = 0; s < TW; ++s) {
+      const int biw = c*TT + wave + kNW*s;
+      if (biw < nt && lane < tile.nout) recs[(wave + kNW*s)*pitch + 4*onodeL[lane] + 3] = Xout[s];
+    }
+    __syncthreads();
+    // ---- node problems of the LDS levels, from the tile's outputs down, (node, tracer) items
+    // spread over all threads
+    for (int lv = tile.nlvl - 1; lv >= 0; --lv) {
+      const int a = lvlL[lv];
+      const int nitems = (lvlL[lv+1] - a) << Log2<TT>::value;
+      for (int q = threadIdx.x; q < nitems; q += kBlock) {
+        const int j = a + (q >> Log2<TT>::value);
+        const uint32_t kk = kidsL[j];
+        const int c0 = kk & 0xffff, c1 = kk >> 16, me = nleaf + j;
+        const KidRho r0{rho[c0], rw[c0], rq[c0]}, r1{rho[c1], rw[c1], rq[c1]};
+        const double* P = R + 4*me;
+        double* K0 = R + 4*c0;
+        double* K1 = R + 4*c1;
+        double x0, x1;
+        node_problem_mass(P[0], P[1], P[2], P[3], r0, K0[0], K0[1], K0[2], r1, K1[0], K1[1], K1[2],
+                          x0, x1, prefer);
+        K0[3] = x0;
+        K1[3] = x1;
+      }
+      __syncthreads();
+    }
+
+    // ---- this wave's tracers again: the micro-subtree's node problems in registers
+#pragma unroll
+    for (int s = 0; s < TW; ++s) {
+      const int biw = c*TT + wave + kNW*s;
+      if (biw >= nt || lane >= nleaf) continue;
+      double T[3], RR[3];  // inner pair t and micro root: {lo, orig, hi} sums, re-formed
+#pragma unroll
+      for (int f = 0; f < 3; ++f) {
+        T[f] = cur[s][0][f] + cur[s][1][f];
+        RR[f] = m.shape <= 0 ? cur[s][0][f] : (m.shape == 1 ? T[f] : T[f] + cur[s][2][f]);
+      }
+      const double Xr = recs[(wave + kNW*s)*pitch + 4*lane + 3];
+      double Xt = Xr, Xu = Xr, Xv = 0, Xp = 0;
+      const KidRho kt{cellrho[9*kWave + lane], cellrho[10*kWave + lane], cellrho[11*kWave + lane]};
+      if ((any2 && m.shape == 2) || (any3 && m.shape == 3)) {
+        const KidRho kp{cellrho[6*kWave + lane], cellrho[7*kWave + lane], cellrho[8*kWave + lane]};
+        if (any2 && m.shape == 2)
+          node_problem_mass(RR[0], RR[1], RR[2], Xr, kt, T[0], T[1], T[2],
+                            kp, cur[s][2][0], cur[s][2][1], cur[s][2][2], Xt, Xp, prefer);
+        if (any3 && m.shape == 3)
+          node_problem_mass(RR[0], RR[1], RR[2], Xr, kp, cur[s][2][0], cur[s][2][1], cur[s][2][2],
+                            kt, T[0], T[1], T[2], Xp, Xt, prefer);
+      }
+      if (m.shape >= 1) {
+        const KidRho ku{cellrho[0*kWave + lane], cellrho[1*kWave + lane], cellrho[2*kWave + lane]};
+        const KidRho kv{cellrho[3*kWave + lane], cellrho[4*kWave + lane], cellrho[5*kWave + lane]};
+        node_problem_mass(T[0], T[1], T[2], Xt, ku, cur[s][0][0], cur[s][0][1], cur[s][0][2],
+                          kv, cur[s][1][0], cur[s][1][1], cur[s][1][2], Xu, Xv, prefer);
+      }
+      double* __restrict__ const orow = (ROWS ? outL[biw] : r2l + static_cast<size_t>(r2lL[biw])*S) + tile.in0;
+      store_roles(orow, ro, Xu, Xv, Xp);
+    }
+  }
 }
 
 // reference cedr_qlt.cpp:453-473 (root_compute), one thread per bulk index.
@@ -1528,6 +1771,23 @@ int cedr_hip_qlt_down_rows (const cedr_hip_qlt_layout* lay, const cedr_hip_stage
       return 0;
     };
     int e;
+    // Every tracer shape preserving: the specialised kernel with the next chunk in flight.
+    static const bool sp_on = [] { const char* v = std::getenv("CEDR_HIP_DOWN_SP"); return ! v || std::atoi(v) != 0; }();
+    if ((lay->flags & CEDR_QLT_ALL_SHAPEPRESERVE) && sp_on) {
+      const size_t ldss = ldsm + sizeof(int32_t)*(2*static_cast<size_t>(nt) + kWave);
+      if (ldss > 160*1024) return static_cast<int>(hipErrorInvalidValue);
+      auto gosp = [&] (auto kernel) -> int {
+        int e2 = set_lds_limit(kernel, ldss);
+        if (e2) return e2;
+        hipLaunchKernelGGL(kernel, gridm, dim3(kBlock), ldss, stream,
+                           *lay, *st, l2r, r2l, in_rows, out_rows, nrow, pitch);
+        return 0;
+      };
+      if (tw == 1) e = in_rows ? gosp(qlt_down_sp_kernel<1, true>) : gosp(qlt_down_sp_kernel<1, false>);
+      else e = in_rows ? gosp(qlt_down_sp_kernel<2, true>) : gosp(qlt_down_sp_kernel<2, false>);
+      if (e) return e;
+      return launch_status();
+    }
     if (tw == 1) e = in_rows ? go(qlt_down_micro_kernel<1, true>) : go(qlt_down_micro_kernel<1, false>);
     else e = in_rows ? go(qlt_down_micro_kernel<2, true>) : go(qlt_down_micro_kernel<2, false>);
     if (e) return e;

@@ -20,43 +20,13 @@ __device__ __forceinline__ double rmin (double a, double b) { return a < b ? a :
 __device__ __forceinline__ double rmax (double a, double b) { return a > b ? a : b; }
 
 // ------------------------------------------------------------------ node math
-// reference cedr_local_inl.hpp:69-165 (solve_1eq_bc_qp_2d) with a = (1, 1).
-// Multiplications and divisions by the constant 1 are dropped: they are exact,
-// so every remaining operation sees the same operands in the same order.
-// w_i = 1/rhom_i and q_i = a_i/w_i = 1/w_i depend only on the node, not on the
-// tracer, so the caller computes them once per node and passes them in.
-__device__ void qp_2d (const double w0, const double w1, const double q0, const double q1,
-                       const double b,
-                       const double lo0, const double lo1, const double hi0, const double hi1,
-                       const double y0, const double y1, double& x0, double& x1,
-                       const bool clip, const bool early_exit_on_tol) {
-  if (early_exit_on_tol) {
-    // calc_r_tol (:14-18) and check_lu (:23-41)
-    double ab = fabs(b);
-    ab = rmax(ab, fabs(y0));
-    ab = rmax(ab, fabs(y1));
-    const double r_tol = 1e1*kEps*fabs(ab);
-    double r = -b;
-    r += lo0; r += lo1;
-    if ( ! (fabs(r) <= r_tol)) {
-      if (r > 0) { x0 = lo0; x1 = lo1; return; }
-      r = -b;
-      r += hi0; r += hi1;
-      if ( ! (fabs(r) <= r_tol) && r < 0) { x0 = hi0; x1 = hi1; return; }
-    }
-  }
-  {
-    double qmass = 0;
-    qmass += q0; qmass += q1;
-    double dm = b;
-    dm -= y0; dm -= y1;
-    const double lambda = dm/qmass;
-    x0 = y0 + lambda*q0;
-    if ( ! (x0 < lo0 || x0 > hi0)) {
-      x1 = y1 + lambda*q1;
-      if ( ! (x1 < lo1 || x1 > hi1)) return;
-    }
-  }
+// The part of solve_1eq_bc_qp_2d (reference cedr_local_inl.hpp:99-165, a = (1, 1)) that runs when
+// the optimum of the unconstrained problem is outside the box: the solution sits where the
+// line x0 + x1 = b crosses one of the box edges.
+__device__ __forceinline__
+void qp_edges (const double w0, const double w1, const double b,
+               const double lo0, const double lo1, const double hi0, const double hi1,
+               const double y0, const double y1, const bool clip, double& x0, double& x1) {
   // Line a'x = b as base + alpha*dir, dir = (-1, 1); intersect the box edges:
   // 0 bottom (x1 = lo1), 1 right (x0 = hi0), 2 top (x1 = hi1), 3 left (x0 = lo0).
   // The reference scans the four alphas for the FIRST minimum and the FIRST
@@ -95,12 +65,12 @@ __device__ void qp_2d (const double w0, const double w1, const double q0, const 
   {
     const double t0 = base - a0, t1 = base + a0;
     const double d0 = y0 - t0, d1 = y1 - t1;
-    obj0 = 0; obj0 += w0*(d0*d0); obj0 += w1*(d1*d1);
+    obj0 = w0*(d0*d0) + w1*(d1*d1);
   }
   {
     const double t0 = base - a1, t1 = base + a1;
     const double d0 = y0 - t0, d1 = y1 - t1;
-    obj1 = 0; obj1 += w0*(d0*d0); obj1 += w1*(d1*d1);
+    obj1 = w0*(d0*d0) + w1*(d1*d1);
   }
   const bool pick0 = obj0 <= obj1;
   // chosen edge ai as masks
@@ -116,6 +86,47 @@ __device__ void qp_2d (const double w0, const double w1, const double q0, const 
   }
   x0 = fixed1 ? other : v;
   x1 = fixed1 ? v : other;
+}
+
+// reference cedr_local_inl.hpp:69-165 (solve_1eq_bc_qp_2d) with a = (1, 1).
+// Multiplications and divisions by the constant 1 are dropped: they are exact,
+// so every remaining operation sees the same operands in the same order.
+// w_i = 1/rhom_i and q_i = a_i/w_i = 1/w_i depend only on the node, not on the
+// tracer, so the caller computes them once per node and passes them in.
+__device__ void qp_2d (const double w0, const double w1, const double q0, const double q1,
+                       const double b,
+                       const double lo0, const double lo1, const double hi0, const double hi1,
+                       const double y0, const double y1, double& x0, double& x1,
+                       const bool clip, const bool early_exit_on_tol) {
+  if (early_exit_on_tol) {
+    // calc_r_tol (:14-18) and check_lu (:23-41)
+    // max(|b|, |y0|, |y1|): for operands that are not NaN, fmax returns the value the reference's
+    // chain of comparisons does (all operands are >= +0, so there is no signed-zero case)
+    const double ab = fmax(fmax(fabs(b), fabs(y0)), fabs(y1));
+    const double r_tol = 1e1*kEps*ab;
+    double r = -b;
+    r += lo0; r += lo1;
+    if ( ! (fabs(r) <= r_tol)) {
+      if (r > 0) { x0 = lo0; x1 = lo1; return; }
+      r = -b;
+      r += hi0; r += hi1;
+      if ( ! (fabs(r) <= r_tol) && r < 0) { x0 = hi0; x1 = hi1; return; }
+    }
+  }
+  {
+    // The reference starts its sums at 0: 0 + q0 is q0 bit for bit unless q0 is -0, and
+    // q0 = 1/(1/rhom) with rhom > 0; likewise the objectives below (w*(d*d) is never -0).
+    const double qmass = q0 + q1;
+    double dm = b;
+    dm -= y0; dm -= y1;
+    const double lambda = dm/qmass;
+    x0 = y0 + lambda*q0;
+    if ( ! (x0 < lo0 || x0 > hi0)) {
+      x1 = y1 + lambda*q1;
+      if ( ! (x1 < lo1 || x1 > hi1)) return;
+    }
+  }
+  qp_edges(w0, w1, b, lo0, lo1, hi0, hi1, y0, y1, clip, x0, x1);
 }
 
 // reference cedr_qlt_inl.hpp:69-99 (r2l_nl_adjust_bounds)
@@ -146,6 +157,9 @@ __device__ void node_problem_mass (const double p_lo, const double p_orig, const
                                    const KidRho r0, double lo0, const double or0, double hi0,
                                    const KidRho r1, double lo1, const double or1, double hi1,
                                    double& x0, double& x1, const bool prefer) {
+#ifdef CEDR_DIAG_NOQP  // diagnostic builds only (wrong results): the sweep without its node problems
+  x0 = or0; x1 = or1; return;
+#endif
   const double rh0 = r0.rh, rh1 = r1.rh;
   const bool below = Qm < p_lo, above = Qm > p_hi;
   if (below || above) {
@@ -163,6 +177,91 @@ __device__ void node_problem_mass (const double p_lo, const double p_orig, const
   x0 = or0;
   x1 = or1;
   qp_2d(r0.w, r1.w, r0.q, r1.q, Qm, lo0, lo1, hi0, hi1, or0, or1, x0, x1, ! prefer, ! prefer);
+}
+
+// N independent node problems of one lane advanced in LOCKSTEP: the same operations on the same
+// operands as N calls of node_problem_mass (bit-identical results), but written as straight-line
+// code over the N problems so that their dependent chains (a dependent fp64 operation waits ~8
+// cycles, an independent one issues every ~4) interleave. The rare paths -- an infeasible node,
+// the corner exits of check_lu -- stay per-problem branches.
+template <int N>
+__device__ __forceinline__
+void node_problems_mass (const double (&p_lo)[N], const double (&p_orig)[N], const double (&p_hi)[N],
+                         const double (&Qm)[N],
+                         const KidRho (&r0)[N], double (&lo0)[N], const double (&or0)[N], double (&hi0)[N],
+                         const KidRho (&r1)[N], double (&lo1)[N], const double (&or1)[N], double (&hi1)[N],
+                         double (&x0)[N], double (&x1)[N], const bool prefer) {
+#ifdef CEDR_DIAG_NOQP
+  for (int i = 0; i < N; ++i) { x0[i] = or0[i]; x1[i] = or1[i]; }
+  return;
+#endif
+  bool quick[N];
+  bool all_quick = true;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const bool below = Qm[i] < p_lo[i], above = Qm[i] > p_hi[i];
+    quick[i] = false;
+    if (below || above) {
+      const double tol = 10*kEps;
+      const double disc = below ? p_lo[i] - Qm[i] : Qm[i] - p_hi[i];
+      if (disc > tol*(p_hi[i] - p_lo[i])) {
+        if (below) adjust_bounds(lo0[i], lo1[i], r0[i].rh, r1[i].rh, Qm[i] - p_lo[i]);
+        else       adjust_bounds(hi0[i], hi1[i], r0[i].rh, r1[i].rh, Qm[i] - p_hi[i]);
+      }
+    } else {
+      quick[i] = Qm[i] == p_orig[i] && or0[i] >= lo0[i] && or0[i] <= hi0[i] && or1[i] >= lo1[i] &&
+        or1[i] <= hi1[i];
+    }
+    all_quick = all_quick && quick[i];
+    x0[i] = or0[i];
+    x1[i] = or1[i];
+  }
+  if (all_quick) return;
+  // solve_1eq_bc_qp_2d for every problem (the quick ones discard it)
+  const bool clip = ! prefer, early = ! prefer;
+  bool exl[N], exh[N], inside[N];
+  double xa[N], xb[N];
+  bool need_edges = false;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    exl[i] = exh[i] = false;
+    if (early) {
+      const double ab = fmax(fmax(fabs(Qm[i]), fabs(or0[i])), fabs(or1[i]));
+      const double r_tol = 1e1*kEps*ab;
+      double r = -Qm[i];
+      r += lo0[i]; r += lo1[i];
+      const bool out = ! (fabs(r) <= r_tol);
+      exl[i] = out && r > 0;
+      double r2 = -Qm[i];
+      r2 += hi0[i]; r2 += hi1[i];
+      exh[i] = out && ! (r > 0) && ! (fabs(r2) <= r_tol) && r2 < 0;
+    }
+    const double qmass = r0[i].q + r1[i].q;
+    double dm = Qm[i];
+    dm -= or0[i]; dm -= or1[i];
+    const double lambda = dm/qmass;
+    xa[i] = or0[i] + lambda*r0[i].q;
+    xb[i] = or1[i] + lambda*r1[i].q;
+    inside[i] = ! (xa[i] < lo0[i] || xa[i] > hi0[i]) && ! (xb[i] < lo1[i] || xb[i] > hi1[i]);
+    need_edges = need_edges || ! (quick[i] || exl[i] || exh[i] || inside[i]);
+  }
+  double e0[N], e1[N];
+  if (need_edges) {
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+      qp_edges(r0[i].w, r1[i].w, Qm[i], lo0[i], lo1[i], hi0[i], hi1[i], or0[i], or1[i], clip, e0[i], e1[i]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < N; ++i) e0[i] = e1[i] = 0;
+  }
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    if (quick[i]) continue;
+    x0[i] = inside[i] ? xa[i] : e0[i];
+    x1[i] = inside[i] ? xb[i] : e1[i];
+    if (exl[i]) { x0[i] = lo0[i]; x1[i] = lo1[i]; }
+    if (exh[i]) { x0[i] = hi0[i]; x1[i] = hi1[i]; }
+  }
 }
 
 // reference cedr_qlt_inl.hpp:175-203 (dispatch on problem type)

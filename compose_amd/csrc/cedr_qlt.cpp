@@ -251,6 +251,12 @@ void QLTHip::finish_setup () {
   d.lay.bidx_l2r = d.bidx_l2r.data();
   d.lay.bidx_r2l = d.bidx_r2l.data();
   d.lay.l2r_op = d.l2r_op.data();
+  d.lay.flags = 0;
+  {
+    bool all_sp = get_num_tracers() > 0;
+    for (const Int pt : md_.trcr2prob) if ( ! (pt & ProblemType::shapepreserve)) all_sp = false;
+    if (all_sp) d.lay.flags |= CEDR_QLT_ALL_SHAPEPRESERVE;
+  }
 }
 
 int QLTHip::get_problem_type (const Int& tracer_idx) const {

@@ -67,7 +67,10 @@ typedef struct {
   const int32_t* bidx_l2r;   /* [nt] first l2r field of the tracer     */
   const int32_t* bidx_r2l;   /* [nt] first r2l field of the tracer     */
   const uint8_t* l2r_op;     /* [l2rndps] 0 sum, 1 min, 2 max per field */
+  int32_t flags;             /* bit 0: every tracer is shape preserving (s, st, cs, cst): the
+                              * root->leaves sweep may use the kernel specialised for that */
 } cedr_hip_qlt_layout;
+enum { CEDR_QLT_ALL_SHAPEPRESERVE = 1 };
 
 /* Leaves->root sweep of `nfields` independent fields over one stage: every
  * internal node gets op(kid0, kid1); only tile roots are written back.
