@@ -249,6 +249,7 @@ void* cedr_plan_create (void* tree, int ncells, int my_rank, int nranks, int max
   if (max_tile_leaves > 0) o.max_tile_leaves = max_tile_leaves;
   if (max_tile_leaves < 0) { o.micro = false; if (max_tile_leaves < -1) o.max_tile_leaves = -max_tile_leaves; }
   if (const char* e = std::getenv("CEDR_HIP_MICRO_CUT")) o.micro_cut = std::atoi(e);
+  if (const char* e = std::getenv("CEDR_HIP_MICRO_CUT2")) o.micro_cut2 = std::atoi(e);
   if (const char* e = std::getenv("CEDR_HIP_MICRO")) o.micro_all = std::atoi(e) >= 2;
   PlanBox* b = new PlanBox();
   b->owned = plan::build(t, my_rank, nranks, leaf_slot, o);

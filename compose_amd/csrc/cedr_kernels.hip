@@ -78,6 +78,15 @@ __device__ __forceinline__ int diag_in0 (const int in0) {
 #endif
 }
 
+// LDS accesses of ONE wave execute in program order, so data a lane wrote can be read by another
+// lane of the same wave without a workgroup barrier; this only keeps the COMPILER from moving LDS
+// accesses across the point (no instruction is generated).
+__device__ __forceinline__ void wave_lds_order () {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 template <int N> struct Log2 { enum { value = 1 + Log2<N/2>::value }; };
 template <> struct Log2<1> { enum { value = 0 }; };
 
@@ -480,7 +489,7 @@ void tree_up_micro_kernel (const cedr_hip_stage st, const int nfields,
   // 3-cell load window would reach past it reads the window cshift cells earlier and
   // picks its cells from the later window positions (fix_window).
   const int cshift = ROWS ? max(0, tile.in0 + m.start + 2 - (nrow - 1)) : 0;
-  const int64_t cell0 = tile.in0 + m.start - cshift;
+  const int64_t cell0 = diag_in0(tile.in0) + m.start - cshift;
   const double* __restrict__ src0 = data + cell0;
   constexpr int NR = FT/kNW;
   // The per-field combine rule, the tile's output node ids and (ROWS) the row
@@ -525,8 +534,6 @@ void tree_up_micro_kernel (const cedr_hip_stage st, const int nfields,
   double ccc[NR], ncc[NR];
   load(blockIdx.y, cab, ccc, false);  // blockIdx.y < nchunks by construction of the grid
   stage_tile_meta(st, tile, kidsL, lvlL);
-  const int ff = threadIdx.x & (FT - 1);
-  double* const vf = v + ff*pitch;
   if constexpr (FT == 8*kNW) { CEDR_WAIT_VM0_8(cab, ccc); }
   else if constexpr (FT == 4*kNW) { CEDR_WAIT_VM0_4(cab, ccc); }
   else { CEDR_WAIT_VM0_2(cab, ccc); }
@@ -535,7 +542,17 @@ void tree_up_micro_kernel (const cedr_hip_stage st, const int nfields,
 
   for (int c = blockIdx.y; c < nchunks; c += gridDim.y) {
     const int cn = c + gridDim.y;
+#ifdef CEDR_UP_NOPREFETCH  // experiment: no chunk in flight during the combines
+    if (c != static_cast<int>(blockIdx.y)) {
+      load(c, cab, ccc, true);
+      if constexpr (FT == 8*kNW) { CEDR_WAIT_VM0_8(cab, ccc); }
+      else if constexpr (FT == 4*kNW) { CEDR_WAIT_VM0_4(cab, ccc); }
+      else { CEDR_WAIT_VM0_2(cab, ccc); }
+    }
+    (void) cn;
+#else
     load(cn < nchunks ? cn : c, nab, ncc, true);  // the last chunk re-reads itself: keeps the count static
+#endif
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
       const int fr = c*FT + wave + kNW*r;
@@ -550,33 +567,45 @@ void tree_up_micro_kernel (const cedr_hip_stage st, const int nfields,
         micro_up_sum(m.shape, wa, wb, wc) : micro_up(m.shape, orow, zero_init, wa, wb, wc);
       if (lane < nleaf) v[(wave + kNW*r)*pitch + lane] = val;
     }
-    const int f = c*FT + ff;
-    const int o = f < nfields ? opL[f] : 0;
     STAMP(1);  // issue prefetch + micro combines
-    __syncthreads();
-    STAMP(2);  // barrier
+    // The LDS tree above the micro-subtree roots, for the NR rows this wave loaded, by this wave
+    // alone: (node, row) items over its 64 lanes, level after level in program order -- a wave's
+    // LDS accesses execute in order, so no workgroup barrier is needed anywhere in the chunk loop
+    // and the four waves of the workgroup run independently of each other.
+    constexpr int LR = Log2<NR>::value;
+    const int rr = lane & (NR - 1);                  // this lane's row among the wave's NR
+    double* const vr = v + (wave + kNW*rr)*pitch;
+    const int fl = c*FT + wave + kNW*rr;             // its field
+    const int o = fl < nfields ? opL[fl] : 0;
     for (int lv = 0; lv < tile.nlvl; ++lv) {
+      wave_lds_order();
       const int a = lvlL[lv];
-      const int nitems = (lvlL[lv+1] - a) << Log2<FT>::value;
-      for (int q = threadIdx.x; q < nitems; q += kBlock) {
-        const int j = a + (q >> Log2<FT>::value);
+      const int nitems = (lvlL[lv+1] - a) << LR;
+      for (int q = lane; q < nitems; q += kWave) {
+        const int j = a + (q >> LR);
         const uint32_t kk = kidsL[j];
-        vf[nleaf + j] = combine(o, zero_init, vf[kk & 0xffff], vf[kk >> 16]);
+        vr[nleaf + j] = combine(o, zero_init, vr[kk & 0xffff], vr[kk >> 16]);
       }
-      __syncthreads();
     }
+    wave_lds_order();
     STAMP(3);  // LDS levels
-    if (f < nfields)
-      for (int k = threadIdx.x >> Log2<FT>::value; k < tile.nout; k += kBlock/FT)
-        data[static_cast<size_t>(f)*stride + tile.out + k] = vf[outL[k]];
-    __syncthreads();
-    STAMP(4);  // outputs + barrier
+    // The wait for the prefetched chunk comes BEFORE this chunk's output stores are issued: vmcnt
+    // counts stores too, so waiting after them would also wait for their write acknowledgements.
+#ifndef CEDR_UP_NOPREFETCH
     if constexpr (FT == 8*kNW) { CEDR_WAIT_VM0_8(nab, ncc); }
     else if constexpr (FT == 4*kNW) { CEDR_WAIT_VM0_4(nab, ncc); }
     else { CEDR_WAIT_VM0_2(nab, ncc); }
+#endif
     STAMP(5);  // wait for the prefetched chunk
+    if (fl < nfields)
+      for (int k = lane >> LR; k < tile.nout; k += kWave/NR)
+        data[static_cast<size_t>(fl)*stride + tile.out + k] = vr[outL[k]];
+    wave_lds_order();  // the next chunk's combines overwrite these rows
+    STAMP(4);  // outputs
+#ifndef CEDR_UP_NOPREFETCH
 #pragma unroll
     for (int r = 0; r < NR; ++r) { cab[r] = nab[r]; ccc[r] = ncc[r]; }
+#endif
   }
 #ifdef CEDR_STAMPS
   if (lane == 0)
@@ -978,15 +1007,6 @@ void qlt_down_micro_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st
 #ifndef CEDR_DOWN_SP_WAVES1
 # define CEDR_DOWN_SP_WAVES1 5  // ... and the 1-tracer-per-wave build
 #endif
-
-// LDS accesses of ONE wave execute in program order, so data a lane wrote can be read by another
-// lane of the same wave without a workgroup barrier; this only keeps the COMPILER from moving LDS
-// accesses across the point (no instruction is generated).
-__device__ __forceinline__ void wave_lds_order () {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 
 template <int TW, bool ROWS>
 __global__ __launch_bounds__(kBlock, TW == 1 ? CEDR_DOWN_SP_WAVES1 : CEDR_DOWN_SP_WAVES2)
@@ -1701,9 +1721,11 @@ int cedr_hip_tree_up_rows (const cedr_hip_stage* st, int32_t nfields, const uint
   if (st->max_nleaf > 256) return static_cast<int>(hipErrorInvalidValue);
   if (in_rows && ( ! st->micro || nrow < 3)) return static_cast<int>(hipErrorInvalidValue);
   const int pitch = pitch_for(st->max_nodes);
-  const size_t lds = sizeof(double)*(meta_doubles(st) + static_cast<size_t>(kUpFT)*pitch) +
+  const size_t lds0 = sizeof(double)*(meta_doubles(st) + static_cast<size_t>(kUpFT)*pitch) +
     (in_rows ? sizeof(double*)*static_cast<size_t>(nfields) : 0) +   // row table
     sizeof(int32_t)*static_cast<size_t>(nfields + 2 + kWave);  // + op table, + output node ids
+  static const size_t lds_pad = [] { const char* v = std::getenv("CEDR_HIP_UP_LDS_PAD"); return v ? static_cast<size_t>(std::atol(v)) : 0; }();
+  const size_t lds = lds0 + lds_pad;  // (experiments: extra LDS bytes per workgroup lower the occupancy)
   if (lds > 160*1024) return static_cast<int>(hipErrorInvalidValue);
   const dim3 grid(st->ntiles, chunk_split(st->ntiles, (nfields + kUpFT - 1)/kUpFT, kSplitUp));
   const dim3 gridx(xcd_grid(st->ntiles), grid.y);  // micro kernels: XCD-contiguous tile ranges
@@ -1755,7 +1777,11 @@ int cedr_hip_qlt_down_rows (const cedr_hip_qlt_layout* lay, const cedr_hip_stage
     // (measured at 1.5M cells: 0.092-0.12 vs 0.137 ms): pick what is cheaper for this
     // tracer count -- in effect 1 per wave only for <= 4 tracers.
     const int nt = lay->nt;
-    int tw = (0.7*((nt + 3)/4) < 1.0*((nt + 7)/8)) ? 1 : 2;
+    // Every tracer shape preserving: the specialised kernel, which is fastest with one tracer per
+    // wave at any tracer count (0.55 vs 0.62 ms at 1.5M cells x 40 tracers: 90 VGPRs, 5 waves/SIMD).
+    static const bool sp_on = [] { const char* v = std::getenv("CEDR_HIP_DOWN_SP"); return ! v || std::atoi(v) != 0; }();
+    const bool sp = (lay->flags & CEDR_QLT_ALL_SHAPEPRESERVE) && sp_on;
+    int tw = (sp || 0.7*((nt + 3)/4) < 1.0*((nt + 7)/8)) ? 1 : 2;
     if (const char* e = std::getenv("CEDR_HIP_MICRO_TW")) tw = std::atoi(e) == 1 ? 1 : 2;
     const int TTm = kNW*tw;
     const size_t ldsm = sizeof(double)*(meta_doubles(st) + 3*mn + kCellRho*kWave +
@@ -1771,9 +1797,7 @@ int cedr_hip_qlt_down_rows (const cedr_hip_qlt_layout* lay, const cedr_hip_stage
       return 0;
     };
     int e;
-    // Every tracer shape preserving: the specialised kernel with the next chunk in flight.
-    static const bool sp_on = [] { const char* v = std::getenv("CEDR_HIP_DOWN_SP"); return ! v || std::atoi(v) != 0; }();
-    if ((lay->flags & CEDR_QLT_ALL_SHAPEPRESERVE) && sp_on) {
+    if (sp) {
       const size_t ldss = ldsm + sizeof(int32_t)*(2*static_cast<size_t>(nt) + kWave);
       if (ldss > 160*1024) return static_cast<int>(hipErrorInvalidValue);
       auto gosp = [&] (auto kernel) -> int {

@@ -20,8 +20,9 @@ struct Builder {
   std::vector<int32_t> first_in; // scratch: local id of a node's first input
   std::vector<char> has_parent;  // scratch: node has a kept parent in the tile
   bool micro_mode = false;     // inputs are micro-subtrees (<= 3 leaves) instead of slots
-  bool cut_stage = false;      // the stage being built cuts its tiles (first stage only: later
-                               // stages are small, and every cut adds a stage = a launch)
+  int32_t stage_cut = 0;       // local levels the tiles of the stage being built keep (0 = all).
+                               // Only the first two stages may be cut: later ones are small, and
+                               // a cut there would add a stage = a launch in each direction.
   int32_t next_slot;
 
   bool is_input (const int32_t n) const {
@@ -132,7 +133,7 @@ struct Builder {
       }
     }
     // Cut tiles keep only the internal nodes of local level <= cut.
-    const int32_t cut = (micro_mode && cut_stage && opt.micro_cut > 0) ? opt.micro_cut : 0;
+    const int32_t cut = (micro_mode && stage_cut > 0) ? stage_cut : 0;
     std::vector<int32_t> dropped;
     if (cut > 0) {
       std::vector<int32_t> keep;
@@ -199,9 +200,9 @@ struct Builder {
   void tile_forest (const std::vector<int32_t>& roots, std::vector<Stage>& stages,
                     const int micro, const bool cut_first) {
     bool first = true;
-    for (;;) {
+    for (int istage = 0;; ++istage) {
       micro_mode = micro == 2 || (micro == 1 && first);
-      cut_stage = first && cut_first;
+      stage_cut = ! cut_first ? 0 : (istage == 0 ? opt.micro_cut : (istage == 1 ? opt.micro_cut2 : 0));
       first = false;
       std::vector<int32_t> active;
       for (const int32_t r : roots) if (slot[r] < 0) active.push_back(r);

@@ -89,7 +89,10 @@ struct Options {
   int32_t max_tile_leaves = 128;  // inputs per tile (bounded by the kernels' LDS use)
   bool micro = true;              // first local stage uses micro tiles (64 x <= 3 leaves)
   bool micro_all = true;          // ... and so does every later stage, over the previous one's outputs
-  int32_t micro_cut = 3;          // local levels kept per micro tile (0 = keep all)
+  int32_t micro_cut = 2;          // local levels kept per micro tile of the FIRST stage (0 = keep all)
+  int32_t micro_cut2 = 2;         // the same for the second stage (micro_all only; 0 = keep all): cutting
+                                  // it moves tree levels from the second to the third stage, which
+                                  // otherwise has only a handful of tiles, at no cost in stages
 };
 
 // 'leaf_slot[n]' gives, for every tree node n that is a leaf owned by my_rank,

@@ -121,6 +121,7 @@ void QLTHip::init (const Parallel::Ptr& p, const Int& ncells, const tree::FlatTr
     popt.micro_all = std::atoi(e) >= 2;
   }
   if (const char* e = std::getenv("CEDR_HIP_MICRO_CUT")) popt.micro_cut = std::atoi(e);
+  if (const char* e = std::getenv("CEDR_HIP_MICRO_CUT2")) popt.micro_cut2 = std::atoi(e);
   eng_.reset(new engine::TreeEngine(p, tree, *ns_, popt));
   mdb_.reset(new std::vector<int>());
   d_.reset(new Impl());

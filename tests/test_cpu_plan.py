@@ -112,7 +112,7 @@ def test_micro_plan_invariants(ca, imbalanced):
         for t in st["tiles"]:
             in0, nleaf, out, nint, koff, loff, nlvl, moff, nout, ooff = [int(x) for x in t]
             assert 1 <= nleaf <= 64 and nint == nleaf - nout
-            assert nlvl <= 3 if si == 0 else nout == 1  # only the first stage cuts its tiles
+            assert nlvl <= 2 if si <= 1 else nout == 1  # only the first two stages cut their tiles (to 2 levels)
             outs = st["outs"][ooff:ooff + nout]
             assert len(set(outs)) == nout and (outs < nleaf + nint).all()
             prev_end = 0
