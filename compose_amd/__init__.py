@@ -151,6 +151,7 @@ _SIGS = {
     "cedr_hip_profile_get": (C.c_int, [C.c_int, _ip, C.POINTER(C.c_int64), C.POINTER(C.c_float)]),
     "cedr_hip_profile_name": (C.c_char_p, [C.c_int]),
     "cedr_local_solve": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, C.c_double, _dp, _dp, _dp, _dp]),
+    "cedr_hip_node_problem_batch": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cedr_hip_local_batch": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_void_p]),
 }
@@ -273,6 +274,20 @@ def local_batch(kind, w, a, b, xlo, xhi, y, clip=True, early_exit_on_tol=True, m
     _chk(lib().cedr_hip_local_batch(kind, nprob, n, flags, max_its, din.ptr, dx.ptr, di.ptr, None), "local_batch")
     synchronize()
     return di.numpy(), dx.numpy((nprob, n))
+
+
+def node_problem_batch(problem_type, rhom, pd, Qm, rhom0, k0d, rhom1, k1d, prefer=False, pair=False):
+    """solve_node_problem (reference cedr_qlt_inl.hpp:120-203) as the sweep kernels evaluate it, one
+    problem per GPU thread. pd, k0d, k1d are [nprob][3]; the rest [nprob]. Returns [nprob][2]."""
+    c = lambda v: np.asarray(v, np.float64).reshape(len(Qm), -1)
+    rec = np.ascontiguousarray(np.concatenate([c(rhom), c(pd), c(Qm), c(rhom0), c(k0d), c(rhom1), c(k1d)], axis=1))
+    assert rec.shape[1] == 13
+    din = DeviceArray.from_numpy(rec)
+    dout = DeviceArray(2 * len(rec))
+    _chk(lib().cedr_hip_node_problem_batch(problem_type, len(rec), int(prefer), int(pair), din.ptr, dout.ptr, None),
+         "node_problem_batch")
+    synchronize()
+    return dout.numpy((len(rec), 2))
 
 
 class Parallel:

@@ -1629,6 +1629,36 @@ __global__ void local_batch_kernel (const int kind, const int nprob, const int n
   for (int i = 0; i < n; ++i) xout[static_cast<size_t>(p)*n + i] = x[i];
 }
 
+__global__ void node_problem_batch_kernel (const int pt, const int nprob, const int prefer, const int pair,
+                                           const double* __restrict__ in, double* __restrict__ out) {
+  const int t = blockIdx.x*blockDim.x + threadIdx.x;
+  auto kid = [] (const double rh) { const double w = 1.0/rh; return KidRho{rh, w, 1.0/w}; };
+  if (pair) {
+    if (2*t + 1 >= nprob) return;
+    double plo[2], por[2], phi[2], qm[2], l0[2], o0[2], h0[2], l1[2], o1[2], h1[2], x0[2], x1[2];
+    KidRho k0[2], k1[2];
+    for (int j = 0; j < 2; ++j) {
+      const double* p = in + 13*static_cast<size_t>(2*t + j);
+      plo[j] = p[1]; por[j] = p[2]; phi[j] = p[3]; qm[j] = p[4];
+      k0[j] = kid(p[5]); l0[j] = p[6]; o0[j] = p[7]; h0[j] = p[8];
+      k1[j] = kid(p[9]); l1[j] = p[10]; o1[j] = p[11]; h1[j] = p[12];
+    }
+    node_problems_mass<2>(plo, por, phi, qm, k0, l0, o0, h0, k1, l1, o1, h1, x0, x1, prefer != 0);
+    for (int j = 0; j < 2; ++j) { out[2*(2*t + j)] = x0[j]; out[2*(2*t + j) + 1] = x1[j]; }
+    return;
+  }
+  if (t >= nprob) return;
+  const double* p = in + 13*static_cast<size_t>(t);
+  double x0, x1;
+  // a nonnegative tracer's record is its mass alone, k*d[0] (cedr_qlt_inl.hpp:190-198); the kernels
+  // keep it in the 'orig' position
+  const bool nn = (pt & NONNEGATIVE) != 0;
+  solve_node(pt, p[0], p[1], p[2], p[3], p[4], kid(p[5]), p[6], nn ? p[6] : p[7], p[8],
+             kid(p[9]), p[10], nn ? p[10] : p[11], p[12], x0, x1, prefer != 0);
+  out[2*t] = x0;
+  out[2*t + 1] = x1;
+}
+
 // ------------------------------------------------------------ launch profiler
 // Optional HIP-event timing of every layer-K launch, on the stream the kernel
 // is launched on. Off by default; bench.py switches it on for its roofline leg.
@@ -2009,6 +2039,16 @@ int cedr_hip_local_batch (int kind, int nprob, int n, int flags, int max_its, co
   if (nprob <= 0) return 0;
   hipLaunchKernelGGL(local_batch_kernel, dim3((nprob + 63)/64), dim3(64), 0, stream, kind, nprob, n, flags,
                      max_its, in_dev, x_dev, info_dev);
+  return launch_status();
+}
+
+int cedr_hip_node_problem_batch (int problem_type, int nprob, int prefer_mass_con, int pair, const double* in_dev,
+                                 double* out_dev, cedr_stream_t stream) {
+  if (nprob <= 0) return 0;
+  if (pair && ( ! (problem_type & SHAPEPRESERVE) || nprob % 2)) return static_cast<int>(hipErrorInvalidValue);
+  const int nthr = pair ? nprob/2 : nprob;
+  hipLaunchKernelGGL(node_problem_batch_kernel, dim3((nthr + 63)/64), dim3(64), 0, stream, problem_type, nprob,
+                     prefer_mass_con, pair, in_dev, out_dev);
   return launch_status();
 }
 

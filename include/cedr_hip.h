@@ -327,6 +327,14 @@ int cedr_local_solve(int kind, int n, int flags, int max_its, const double* w, c
 int cedr_hip_local_batch(int kind, int nprob, int n, int flags, int max_its, const double* in_dev,
                          double* x_dev, int32_t* info_dev, cedr_stream_t stream);
 
+/* The node problem of the root->leaves sweep (reference cedr_qlt_inl.hpp:120-203 solve_node_problem),
+ * exactly as the sweep kernels evaluate it (cedr_node_math.hpp), one problem per GPU thread: a direct
+ * handle for parity tests. Problem p: in[13p ..] = rhom, pd[3], Qm, rhom0, k0d[3], rhom1, k1d[3];
+ * out[2p ..] = Qm0, Qm1. pair != 0 solves problems 2i and 2i+1 with the lockstep form
+ * (node_problems_mass<2>; shape-preserving problem types only). */
+int cedr_hip_node_problem_batch(int problem_type, int nprob, int prefer_mass_con, int pair, const double* in_dev,
+                                double* out_dev, cedr_stream_t stream);
+
 /* -- device memory helpers for hosts without their own HIP bindings ---------- */
 int cedr_device_count(void);
 void* cedr_malloc(size_t bytes);
