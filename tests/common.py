@@ -86,3 +86,32 @@ def run_hip_caas(ca, ncells, types, v, external_memory=False, user_reducer=None,
     c.get_Qm(out_d)
     ca.synchronize()
     return out_d.numpy(v.Qm.shape)
+
+
+def rel_per_tracer(got, want):
+    """max_i |got - want| / max_i |want| for every tracer (row)."""
+    return np.abs(got - want).max(axis=1) / np.abs(want).max(axis=1)
+
+
+def caas_exact_sums(v, tracers):
+    """CAAS (reference cedr_caas.cpp:129-253: clip; four sums; redistribute) for the given tracers
+    with every sum EXACTLY rounded (math.fsum) -- what a summation of unbounded precision gives.
+    Conserving, shape-preserving tracers (the throughput configuration)."""
+    import math
+    out = np.empty((len(tracers), v.Qm.shape[1]))
+    for k, t in enumerate(tracers):
+        lo, hi = v.Qm_min[t], v.Qm_max[t]
+        clip = np.maximum(lo, np.minimum(hi, v.Qm[t]))
+        s_clip, s_prev = math.fsum(clip), math.fsum(v.Qm_prev[t])
+        m = s_prev - s_clip
+        x = clip.copy()
+        if m < 0:
+            fac = s_clip - math.fsum(lo)
+            if fac > 0:
+                x = np.maximum(lo, clip + (m / fac) * (clip - lo))
+        elif m > 0:
+            fac = math.fsum(hi) - s_clip
+            if fac > 0:
+                x = np.minimum(hi, clip + (m / fac) * (hi - clip))
+        out[k] = x
+    return out

@@ -39,7 +39,7 @@ def test_rccl_single_rank(gpu, oracle):
     ca.synchronize()
     want, _ = common.run_oracle_caas(oracle, [3000], types, v)
     got = out.numpy(v.Qm.shape)
-    assert np.abs(got - want).max() / np.abs(want).max() <= 1e-13
+    assert common.rel_per_tracer(got, want).max() <= 1e-13
 
 
 def _bench(args, timeout=600):
