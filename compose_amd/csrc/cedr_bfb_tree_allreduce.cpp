@@ -91,6 +91,11 @@ void BfbTreeAllReducerHip::allreduce (const Real* send, Real* recv, const bool t
     cedr_k_check(cedr_hip_scatter_slots(bd, S, nfield_, m_->leaf_slots.data(), nlocal_, send, s));
   }
   // Every node is 0 + kid0 + kid1, as in cedr_bfb_tree_allreduce.cpp:117-123.
+  if (eng_->has_apex()) {  // multi-rank, small replicated top: one launch after the all-gather
+    const Real* const gathered = eng_->up_to_exchange(nfield_, m_->op.data(), bd, true, s, in_rows);
+    cedr_k_check(cedr_hip_tree_apex_sum(eng_->apex_stage(), gathered, eng_->apex_src(), nfield_, 1, recv, s));
+    return;
+  }
   eng_->up(nfield_, m_->op.data(), bd, true, s, in_rows);
   // The root's record is the result on every rank (:68-76 read it back from
   // the first leaf after the root->leaves copies; the value is the same).

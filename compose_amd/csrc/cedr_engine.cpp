@@ -1,5 +1,7 @@
 #include "cedr_engine.hpp"
 
+#include <cstdlib>
+
 
 namespace cedr {
 namespace engine {
@@ -72,6 +74,24 @@ void TreeEngine::upload () {
     my_top_slots_.upload(plan_.my_top_slots);
     gather_slots_.upload(plan_.gather_slots);
   }
+  static const bool apex_on = [] { const char* v = std::getenv("CEDR_HIP_APEX"); return ! v || std::atoi(v) != 0; }();
+  if (apex_on && ! plan_.apex.tiles.empty()) {
+    apex_.reset(new DeviceStage());
+    apex_->upload(plan_.apex);
+    // input i of the apex tile is top slot in0 + i; which gathered record holds it?
+    const plan::Tile& t = plan_.apex.tiles[0];
+    std::vector<int32_t> src(t.nleaf, -1), mine;
+    for (size_t q = 0; q < plan_.gather_slots.size(); ++q) {
+      const int32_t s = plan_.gather_slots[q];
+      if (s < 0) continue;
+      cedr_throw_if(s < t.in0 || s >= t.in0 + t.nleaf, "apex tile does not cover a boundary root");
+      src[s - t.in0] = static_cast<int32_t>(q);
+    }
+    for (const int32_t v : src) cedr_throw_if(v < 0, "apex input without a gathered record");
+    for (const int32_t s : plan_.my_top_slots) mine.push_back(s - t.in0);
+    apex_src_.upload(src);
+    apex_my_in_.upload(mine);
+  }
   uploaded_ = true;
 }
 
@@ -92,6 +112,15 @@ void TreeEngine::up (int32_t nfields, const uint8_t* op_dev, double* data, bool 
     cedr_k_check(cedr_hip_tree_up_rows(&local_[i]->h, nfields, op_dev, stride_, data,
                                        i == 0 ? in_rows : nullptr, plan_.nlcl, zero_init, stream));
   if (top_.empty()) return;
+  exchange(nfields, data, stream);
+  cedr_k_check(cedr_hip_scatter_slots(data, stride_, nfields, gather_slots_.data(),
+                                      plan_.nranks*plan_.nb_max, recvbuf_.data(), stream));
+  for (const auto& st : top_)
+    cedr_k_check(cedr_hip_tree_up(&st->h, nfields, op_dev, stride_, data, zero_init, stream));
+}
+
+// Gather this rank's boundary roots and all-gather them: recvbuf_ = [rank][nb_max][nfields].
+void TreeEngine::exchange (int32_t nfields, double* data, hipStream_t stream) {
   const int32_t P = plan_.nranks, nb = plan_.nb_max;
   if (nfields > xfields_) {
     sendbuf_.alloc_zero(static_cast<size_t>(nb)*nfields);
@@ -104,10 +133,17 @@ void TreeEngine::up (int32_t nfields, const uint8_t* op_dev, double* data, bool 
   const int err = p_->comm()->allgather(sendbuf_.data(), recvbuf_.data(),
                                         static_cast<size_t>(nb)*nfields, stream);
   cedr_throw_if(err != 0, "allgather of subtree roots returned " << err);
-  cedr_k_check(cedr_hip_scatter_slots(data, stride_, nfields, gather_slots_.data(), P*nb,
-                                      recvbuf_.data(), stream));
-  for (const auto& st : top_)
-    cedr_k_check(cedr_hip_tree_up(&st->h, nfields, op_dev, stride_, data, zero_init, stream));
+}
+
+const double* TreeEngine::up_to_exchange (int32_t nfields, const uint8_t* op_dev, double* data,
+                                          bool zero_init, hipStream_t stream,
+                                          const double* const* in_rows) {
+  cedr_throw_if( ! uploaded_ || ! apex_, "up_to_exchange needs an uploaded plan with an apex tile");
+  for (size_t i = 0; i < local_.size(); ++i)
+    cedr_k_check(cedr_hip_tree_up_rows(&local_[i]->h, nfields, op_dev, stride_, data,
+                                       i == 0 ? in_rows : nullptr, plan_.nlcl, zero_init, stream));
+  exchange(nfields, data, stream);
+  return recvbuf_.data();
 }
 
 void TreeEngine::top_to_local (int32_t nfields, double* data, hipStream_t stream) {

@@ -45,6 +45,18 @@ public:
   // its inputs from in_rows[f][slot] instead of data (zero-copy mode).
   void up(int32_t nfields, const uint8_t* op_dev, double* data, bool zero_init,
           hipStream_t stream, const double* const* in_rows = nullptr);
+  // Multi-rank runs whose replicated top fits one apex tile (plan::Plan::apex): the leaves->root
+  // sweep stops at the exchange -- local stages, gather of this rank's boundary roots, ONE
+  // all-gather -- and returns the gathered records [record][nfields] for the apex kernels
+  // (cedr_hip_qlt_apex / cedr_hip_tree_apex_sum), which do the rest in one launch.
+  bool has_apex () const { return apex_ != nullptr; }
+  const double* up_to_exchange(int32_t nfields, const uint8_t* op_dev, double* data, bool zero_init,
+                               hipStream_t stream, const double* const* in_rows = nullptr);
+  const cedr_hip_stage* apex_stage () const { return &apex_->h; }
+  const int32_t* apex_src () const { return apex_src_.data(); }       // record of every apex input
+  const int32_t* apex_my_in () const { return apex_my_in_.data(); }   // apex inputs that are my roots
+  const int32_t* my_root_slots_dev () const { return my_root_slots_.data(); }
+  int32_t n_my_roots () const { return static_cast<int32_t>(plan_.my_root_slots.size()); }
   // Whether the first local stage can read through a row table (it must be a micro stage).
   bool first_stage_takes_rows () const;
 
@@ -59,7 +71,9 @@ private:
   plan::Plan plan_;
   int64_t stride_;
   std::vector<std::unique_ptr<DeviceStage> > local_, top_;
-  dev::Buffer<int32_t> my_root_slots_, my_top_slots_, gather_slots_;
+  std::unique_ptr<DeviceStage> apex_;
+  dev::Buffer<int32_t> my_root_slots_, my_top_slots_, gather_slots_, apex_src_, apex_my_in_;
+  void exchange(int32_t nfields, double* data, hipStream_t stream);
   dev::Buffer<double> sendbuf_, recvbuf_;
   int32_t xfields_ = 0;
   bool uploaded_ = false;

@@ -1224,6 +1224,151 @@ __global__ void qlt_root_kernel (const cedr_hip_qlt_layout L, const int root_slo
   }
 }
 
+// ------------------------------------------------------------------- apex
+// Multi-rank runs: the part of the tree above the ranks' pure subtrees is tiny (P boundary
+// roots for a contiguous P-way sharding) and replicated on every rank. After the all-gather of
+// the boundary roots' records ONE workgroup does everything that part needs, in one launch:
+// unpack the gathered records, sweep them up to the global root, root_compute
+// (cedr_qlt.cpp:441-476), sweep the node problems down (:525-604), and write the assigned masses
+// of THIS rank's boundary roots to their local r2l slots. It replaces five launches (scatter, top
+// leaves->root sweep, root, top root->leaves sweep, copy) -- latency, not bandwidth.
+// Record slots per (node, tracer): 0 lo / q_min, 1 orig (a nonnegative tracer's mass), 2 hi / q_max,
+// 3 Qm_prev sum on the way up (conserving tracers), the assigned mass X on the way down.
+// TT tracers per pass (runtime: all of them when they fit in LDS).
+__global__ __launch_bounds__(kBlock)
+void qlt_apex_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st,
+                      const double* __restrict__ recv, const int32_t* __restrict__ src,
+                      const int nmine, const int32_t* __restrict__ my_in,
+                      const int32_t* __restrict__ my_slot, double* __restrict__ r2l,
+                      const int TT, const int pitch) {
+  extern __shared__ double lds[];
+  const cedr_hip_tile tile = st.tiles[0];
+  const int nleaf = tile.nleaf, MN = st.max_nodes, nf = L.l2rndps, nt = L.nt;
+  uint32_t* const kidsL = reinterpret_cast<uint32_t*>(lds);
+  int32_t* const lvlL = reinterpret_cast<int32_t*>(kidsL + st.max_nint);
+  double* const rho = lds + (st.max_nint + 1);
+  double* const rw = rho + MN;
+  double* const rq = rw + MN;
+  double* const recs = rq + MN;
+  const int64_t S = L.stride;
+  const bool prefer = L.prefer_mass_con != 0;
+  const int root = st.outs[tile.outs_off];
+  for (int i = threadIdx.x; i < nleaf; i += kBlock) rho[i] = recv[static_cast<size_t>(src[i])*nf];
+  stage_tile_meta(st, tile, kidsL, lvlL);
+  __syncthreads();
+  for (int lv = 0; lv < tile.nlvl; ++lv) {
+    const int a = lvlL[lv], b = lvlL[lv+1];
+    for (int j = a + threadIdx.x; j < b; j += kBlock) {
+      const uint32_t kk = kidsL[j];
+      rho[nleaf + j] = rho[kk & 0xffff] + rho[kk >> 16];
+    }
+    __syncthreads();
+  }
+  for (int i = threadIdx.x; i < nleaf + tile.nint; i += kBlock) {
+    const double w = 1.0/rho[i];
+    rw[i] = w;
+    rq[i] = 1.0/w;
+  }
+  for (int c0 = 0; c0 < nt; c0 += TT) {
+    const int ntc = min(TT, nt - c0);
+    // gathered records -> LDS
+    for (int q = threadIdx.x; q < nleaf*ntc*4; q += kBlock) {
+      const int k = q & 3, i = (q >> 2) % nleaf, tt = (q >> 2)/nleaf;
+      const int pt = L.bidx_prob[c0 + tt], lb = L.bidx_l2r[c0 + tt];
+      int field = -1;
+      if (pt & NONNEGATIVE) { if (k == 1) field = lb; else if (k == 3 && (pt & CONSERVE)) field = lb + 1; }
+      else if (k < 3 || (pt & CONSERVE)) field = lb + k;
+      recs[tt*pitch + 4*i + k] = field >= 0 ? recv[static_cast<size_t>(src[i])*nf + field] : 0.0;
+    }
+    __syncthreads();
+    // leaves -> root: sums, except q_min / q_max of a consistent-only tracer (cedr_qlt.cpp:375-383)
+    for (int lv = 0; lv < tile.nlvl; ++lv) {
+      const int a = lvlL[lv], nn = lvlL[lv+1] - a;
+      for (int q = threadIdx.x; q < nn*ntc*4; q += kBlock) {
+        const int k = q & 3, j = a + (q >> 2) % nn, tt = (q >> 2)/nn;
+        const int pt = L.bidx_prob[c0 + tt];
+        const bool t_only = (pt & CONSISTENT) && ! (pt & SHAPEPRESERVE);
+        const uint32_t kk = kidsL[j];
+        double* const R = recs + tt*pitch;
+        const double k0 = R[4*(kk & 0xffff) + k], k1 = R[4*(kk >> 16) + k];
+        R[4*(nleaf + j) + k] = (t_only && k == 0) ? rmin(k0, k1) : ((t_only && k == 2) ? rmax(k0, k1) : k0 + k1);
+      }
+      __syncthreads();
+    }
+    // root_compute: the root's assigned mass is its Qm_prev sum (conserving) or its Qm sum
+    for (int tt = threadIdx.x; tt < ntc; tt += kBlock) {
+      double* const R = recs + tt*pitch;
+      if ( ! (L.bidx_prob[c0 + tt] & CONSERVE)) R[4*root + 3] = R[4*root + 1];
+    }
+    __syncthreads();
+    // root -> leaves
+    for (int lv = tile.nlvl - 1; lv >= 0; --lv) {
+      const int a = lvlL[lv], nn = lvlL[lv+1] - a;
+      for (int q = threadIdx.x; q < nn*ntc; q += kBlock) {
+        const int j = a + q % nn, tt = q/nn;
+        const int pt = L.bidx_prob[c0 + tt];
+        const bool t_only = (pt & CONSISTENT) && ! (pt & SHAPEPRESERVE);
+        double* const R = recs + tt*pitch;
+        const uint32_t kk = kidsL[j];
+        const int c0n = kk & 0xffff, c1n = kk >> 16, me = nleaf + j;
+        const KidRho r0{rho[c0n], rw[c0n], rq[c0n]}, r1{rho[c1n], rw[c1n], rq[c1n]};
+        const double* P = R + 4*me;
+        double* K0 = R + 4*c0n;
+        double* K1 = R + 4*c1n;
+        double x0, x1;
+        if (t_only) {
+          const double qlo = R[4*root], qhi = R[4*root + 2];
+          solve_node(pt, rho[me], qlo, P[1], qhi, P[3], r0, qlo, K0[1], qhi, r1, qlo, K1[1], qhi, x0, x1, prefer);
+        } else {
+          solve_node(pt, rho[me], P[0], P[1], P[2], P[3], r0, K0[0], K0[1], K0[2], r1, K1[0], K1[1], K1[2],
+                     x0, x1, prefer);
+        }
+        K0[3] = x0;
+        K1[3] = x1;
+      }
+      __syncthreads();
+    }
+    // this rank's boundary roots: assigned mass (and a consistent-only tracer's global q bounds,
+    // which travel root->leaves unchanged) to their local slots
+    for (int q = threadIdx.x; q < nmine*ntc; q += kBlock) {
+      const int j = q % nmine, tt = q/nmine;
+      const int pt = L.bidx_prob[c0 + tt], rb = L.bidx_r2l[c0 + tt];
+      const double* const R = recs + tt*pitch;
+      r2l[static_cast<size_t>(rb)*S + my_slot[j]] = R[4*my_in[j] + 3];
+      if ((pt & CONSISTENT) && ! (pt & SHAPEPRESERVE)) {
+        r2l[static_cast<size_t>(rb + 1)*S + my_slot[j]] = R[4*root];
+        r2l[static_cast<size_t>(rb + 2)*S + my_slot[j]] = R[4*root + 2];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// The same for a plain sum of 'nfields' fields (BfbTreeAllReducer): one thread per field walks the
+// whole (tiny) tree in its own LDS column -- no barriers -- and writes the root's value.
+__global__ __launch_bounds__(kBlock)
+void tree_apex_sum_kernel (const cedr_hip_stage st, const double* __restrict__ recv,
+                           const int32_t* __restrict__ src, const int nfields, const int zero_init,
+                           double* __restrict__ out, const int pitch, const int ncols) {
+  extern __shared__ double lds[];
+  const cedr_hip_tile tile = st.tiles[0];
+  const int nleaf = tile.nleaf;
+  const uint16_t* __restrict__ kids = st.kids + 2*static_cast<size_t>(tile.kids_off);
+  const int root = st.outs[tile.outs_off];
+  if (static_cast<int>(threadIdx.x) >= ncols) return;  // LDS holds ncols columns
+  for (int f = threadIdx.x; f < nfields; f += ncols) {
+    double* const v = lds + static_cast<size_t>(threadIdx.x)*pitch;
+    for (int i = 0; i < nleaf; ++i) v[i] = recv[static_cast<size_t>(src[i])*nfields + f];
+    for (int j = 0; j < tile.nint; ++j) {  // kids come before parents in the tile's node order
+      const double k0 = v[kids[2*j]], k1 = v[kids[2*j + 1]];
+      double r;
+      if (zero_init) { r = 0; r += k0; r += k1; } else r = k0 + k1;
+      v[nleaf + j] = r;
+    }
+    out[f] = v[root];
+  }
+}
+
 // ----------------------------------------------------------- slot shuffles
 __global__ void gather_slots_kernel (const double* __restrict__ data, const int64_t stride,
                                      const int nfields, const int32_t* __restrict__ slots,
@@ -1664,12 +1809,12 @@ __global__ void node_problem_batch_kernel (const int pt, const int nprob, const 
 // is launched on. Off by default; bench.py switches it on for its roofline leg.
 enum KernelId : int { K_TREE_UP = 0, K_QLT_DOWN, K_QLT_ROOT, K_GATHER, K_SCATTER, K_COPY,
                       K_SET_RHOM, K_SET_QM, K_GET_QM, K_CAAS_REDUCE, K_CAAS_SUM, K_CAAS_ACCUM,
-                      K_CAAS_FINISH, K_COUNT };
+                      K_CAAS_FINISH, K_APEX, K_COUNT };
 const char* const kKernelNames[K_COUNT] = {
   "tree_up_kernel", "qlt_down_kernel", "qlt_root_kernel", "gather_slots_kernel",
   "scatter_slots_kernel", "copy_slots_kernel", "qlt_set_rhom_kernel", "qlt_set_Qm_kernel",
   "qlt_get_Qm_kernel", "caas_reduce_kernel", "caas_sum_partials_kernel",
-  "caas_reduce_accum_kernel", "caas_finish_kernel" };
+  "caas_reduce_accum_kernel", "caas_finish_kernel", "apex_kernel" };
 
 struct ProfRec { int id; int64_t aux; hipEvent_t a, b; };
 struct Profiler {
@@ -1861,6 +2006,39 @@ int cedr_hip_qlt_down_rows (const cedr_hip_qlt_layout* lay, const cedr_hip_stage
     hipLaunchKernelGGL((qlt_down_kernel<kDownTT, 4>), grid, dim3(kBlock), lds, stream,
                        *lay, *st, l2r, r2l, pitch);
   }
+  return launch_status();
+}
+
+int cedr_hip_qlt_apex (const cedr_hip_qlt_layout* lay, const cedr_hip_stage* st, const double* recv,
+                       const int32_t* src, int32_t nmine, const int32_t* my_in, const int32_t* my_slot,
+                       double* r2l, cedr_stream_t stream) {
+  ProfScope ps(K_APEX, st->ntiles, stream);
+  if (st->ntiles != 1 || st->micro || st->max_nleaf > 64) return static_cast<int>(hipErrorInvalidValue);
+  const size_t mn = st->max_nodes;
+  const int pitch = static_cast<int>(4*mn) | 1;
+  // all tracers in one pass if their records fit in 48 KB of LDS, else as many as do
+  const size_t per = sizeof(double)*static_cast<size_t>(pitch);
+  int tt = static_cast<int>((48*1024)/per);
+  if (tt < 1) return static_cast<int>(hipErrorInvalidValue);
+  if (tt > lay->nt) tt = lay->nt;
+  const size_t lds = sizeof(double)*(meta_doubles(st) + 3*mn) + per*tt;
+  int e = set_lds_limit(qlt_apex_kernel, lds);
+  if (e) return e;
+  hipLaunchKernelGGL(qlt_apex_kernel, dim3(1), dim3(kBlock), lds, stream, *lay, *st, recv, src, nmine, my_in,
+                     my_slot, r2l, tt, pitch);
+  return launch_status();
+}
+
+int cedr_hip_tree_apex_sum (const cedr_hip_stage* st, const double* recv, const int32_t* src, int32_t nfields,
+                            int zero_init, double* out, cedr_stream_t stream) {
+  ProfScope ps(K_APEX, st->ntiles, stream);
+  if (st->ntiles != 1 || st->micro || st->max_nleaf > 64) return static_cast<int>(hipErrorInvalidValue);
+  const int pitch = st->max_nodes | 1;
+  int ncols = static_cast<int>((48*1024)/(sizeof(double)*pitch));
+  if (ncols > kBlock) ncols = kBlock;
+  const size_t lds = sizeof(double)*static_cast<size_t>(pitch)*ncols;
+  hipLaunchKernelGGL(tree_apex_sum_kernel, dim3(1), dim3(kBlock), lds, stream, *st, recv, src, nfields, zero_init,
+                     out, pitch, ncols);
   return launch_status();
 }
 

@@ -50,8 +50,10 @@ const RcclApi& rccl () {
     api.ok = false;
     void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    // RTLD_LOCAL: a process that later loads ANOTHER librccl (PyTorch bundles its own) must not
+    // have that copy's symbols resolved against this one (seen as a double free at exit).
     for (size_t i = 0; ! h && i < sizeof(names)/sizeof(*names); ++i)
-      h = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
+      h = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
     if ( ! h) return;
     api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
     api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(dlsym(h, "ncclCommInitRank"));

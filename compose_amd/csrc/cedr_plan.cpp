@@ -296,6 +296,16 @@ Plan build (const tree::FlatTree& t, int32_t my_rank, int32_t nranks,
       p.gather_slots[static_cast<size_t>(own[r])*p.nb_max + per_rank[own[r]]++] = ts;
       if (own[r] == my_rank) p.my_top_slots.push_back(ts);
     }
+    if (static_cast<int32_t>(broots.size()) <= Plan::kApexMaxInputs) {
+      // build_tile does not touch 'slot' (tile_forest applies 'pending' afterwards): undo the rest
+      const int32_t keep_next = b.next_slot;
+      b.micro_mode = false;
+      b.stage_cut = 0;
+      b.pending.clear();
+      b.build_tile(p.apex, 0);
+      b.pending.clear();
+      b.next_slot = keep_next;
+    }
     b.tile_forest(std::vector<int32_t>(1, 0), p.top, (opt.micro && opt.micro_all) ? 2 : 0, false);
   }
   p.root_slot = b.slot[0];

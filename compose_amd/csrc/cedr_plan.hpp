@@ -74,6 +74,11 @@ struct Plan {
   int32_t nslots = 0;     // slots used by this plan
   std::vector<Stage> local;  // stages over this rank's pure subtrees, leaf-most first
   std::vector<Stage> top;    // replicated stages above the pure subtrees (empty if 1 rank)
+  // The same replicated part as ONE plain tile over all boundary roots (inputs = the top input
+  // slots in order, one output = the global root), when there are at most kApexMaxInputs of them:
+  // the single-workgroup "apex" kernels sweep it up and down in one launch. Empty otherwise.
+  Stage apex;
+  static constexpr int32_t kApexMaxInputs = 64;
   int32_t root_slot = 0;     // slot of the global root's record on this rank
 
   // Boundary exchange (unused when nranks == 1). A boundary root is the root

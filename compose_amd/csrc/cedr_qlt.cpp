@@ -358,12 +358,22 @@ void QLTHip::run () {
                                        d.b_qm + ti*n, d.b_min + ti*n, d.b_max + ti*n,
                                        d.b_prev ? d.b_prev + ti*n : nullptr, o.l2r_data, s));
   }
-  eng_->up(d.lay.l2rndps, d.lay.l2r_op, d.l2r, false, s, rows_mode ? d.in_rows.data() : nullptr);
-  cedr_k_check(cedr_hip_qlt_root(&d.lay, eng_->get_plan().root_slot, d.l2r, d.r2l, s));
-  const auto& top = eng_->top_stages();
-  for (size_t i = top.size(); i > 0; --i)
-    cedr_k_check(cedr_hip_qlt_down(&d.lay, &top[i-1]->h, d.l2r, d.r2l, s));
-  eng_->top_to_local(d.lay.r2lndps, d.r2l, s);
+  if (eng_->has_apex()) {
+    // Ranks own whole subtrees and the tree above them is small: after the local sweeps and the
+    // ONE all-gather, one single-workgroup launch does the replicated top (both directions and
+    // root_compute) and hands this rank's boundary roots their masses.
+    const Real* const recv = eng_->up_to_exchange(d.lay.l2rndps, d.lay.l2r_op, d.l2r, false, s,
+                                                  rows_mode ? d.in_rows.data() : nullptr);
+    cedr_k_check(cedr_hip_qlt_apex(&d.lay, eng_->apex_stage(), recv, eng_->apex_src(), eng_->n_my_roots(),
+                                   eng_->apex_my_in(), eng_->my_root_slots_dev(), d.r2l, s));
+  } else {
+    eng_->up(d.lay.l2rndps, d.lay.l2r_op, d.l2r, false, s, rows_mode ? d.in_rows.data() : nullptr);
+    cedr_k_check(cedr_hip_qlt_root(&d.lay, eng_->get_plan().root_slot, d.l2r, d.r2l, s));
+    const auto& top = eng_->top_stages();
+    for (size_t i = top.size(); i > 0; --i)
+      cedr_k_check(cedr_hip_qlt_down(&d.lay, &top[i-1]->h, d.l2r, d.r2l, s));
+    eng_->top_to_local(d.lay.r2lndps, d.r2l, s);
+  }
   const auto& loc = eng_->local_stages();
   for (size_t i = loc.size(); i > 0; --i) {
     const bool rows = rows_mode && i == 1;

@@ -107,6 +107,20 @@ int cedr_hip_qlt_down_rows(const cedr_hip_qlt_layout* lay, const cedr_hip_stage*
 int cedr_hip_qlt_root(const cedr_hip_qlt_layout* lay, int32_t root_slot,
                       const double* l2r, double* r2l, cedr_stream_t stream);
 
+/* Multi-rank runs, after the all-gather of the boundary roots' records: everything the replicated
+ * top of the tree needs, in ONE single-workgroup launch (it replaces scatter + the top sweeps +
+ * cedr_hip_qlt_root + copy; reference: the levels above the rank boundaries in QLT::run,
+ * cedr_qlt.cpp:618-640, and root_compute :441-476). `apex` is a stage of exactly one plain tile
+ * whose nleaf (<= 64) inputs are the boundary roots; recv holds the gathered records
+ * [record][l2rndps]; src[i] = record of input i; this rank's nmine boundary roots are inputs
+ * my_in[j] and get their assigned masses written to r2l slot my_slot[j]. */
+int cedr_hip_qlt_apex(const cedr_hip_qlt_layout* lay, const cedr_hip_stage* apex, const double* recv,
+                      const int32_t* src, int32_t nmine, const int32_t* my_in, const int32_t* my_slot,
+                      double* r2l, cedr_stream_t stream);
+/* The same for a plain sum of nfields fields (BfbTreeAllReducer): out[f] = the root's value. */
+int cedr_hip_tree_apex_sum(const cedr_hip_stage* apex, const double* recv, const int32_t* src, int32_t nfields,
+                           int zero_init, double* out, cedr_stream_t stream);
+
 /* Boundary exchange helpers (replace the per-level MPI messages of
  * cedr_qlt.cpp:327-337,432-439,478-488,606-613):
  * gather : out[j*nfields + f] = data[f*stride + slots[j]], j < n

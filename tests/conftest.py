@@ -31,6 +31,12 @@ def ca():
 
 @pytest.fixture(scope="session")
 def gpu(ca):
+    # Some GPU tests use torch (device tensors, bench.py): import it before the library resolves
+    # librccl, so that one process never ends up with two different copies of RCCL.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if ca.device_count() < 1:
         pytest.fail("no GPU visible: -m gpu tests must run on the GPU box")
     return ca

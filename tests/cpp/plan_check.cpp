@@ -95,6 +95,23 @@ static void check (const tree::FlatTree& t, const int ncells, const int nranks, 
     for (size_t i = 0; i < pl.local.size(); ++i) check_stage(pl.local[i], pl, stride, i == 0, ctx);
     for (size_t i = 0; i < pl.top.size(); ++i) check_stage(pl.top[i], pl, stride, false, ctx);
     REQUIRE(pl.root_slot >= 0 && pl.root_slot < pl.nslots);
+    if ( ! pl.apex.tiles.empty()) {
+      // the apex kernels' preconditions: one plain tile, <= 64 inputs = exactly the boundary roots'
+      // top slots (every one covered by a gathered record), one output
+      REQUIRE(pl.apex.tiles.size() == 1 && pl.apex.micro.empty());
+      const plan::Tile& a = pl.apex.tiles[0];
+      REQUIRE(a.nleaf <= plan::Plan::kApexMaxInputs && a.nout == 1 && a.nint == a.nleaf - 1);
+      check_stage(pl.apex, pl, stride, false, ctx);
+      std::set<int> covered;
+      for (const int s : pl.gather_slots) if (s >= 0) { REQUIRE(s >= a.in0 && s < a.in0 + a.nleaf); covered.insert(s); }
+      REQUIRE((int) covered.size() == a.nleaf);
+      for (const int s : pl.my_top_slots) REQUIRE(s >= a.in0 && s < a.in0 + a.nleaf);
+      REQUIRE(pl.apex.outs[a.outs_off] == a.nleaf + a.nint - 1 || a.nint == 0);
+    } else if (nranks > 1 && ! pl.top.empty()) {
+      int nb = 0;
+      for (const int s : pl.gather_slots) nb += s >= 0;
+      REQUIRE(nb > plan::Plan::kApexMaxInputs);  // the apex tile is only left out when it would be too large
+    }
     if (nranks > 1) {
       REQUIRE((int) pl.gather_slots.size() == nranks*pl.nb_max);
       REQUIRE(pl.my_root_slots.size() == pl.my_top_slots.size());
@@ -122,10 +139,11 @@ int main () {
           const tree::FlatTree t = tree::oned::make_flat_tree(m, imb != 0);
           for (const int tile : {2, 3, 16, 128, 256})
             for (const int micro : {0, 1})
-              for (const int cut : {0, 1, 3, 5}) {
+              for (const int cut : {0, 1, 2, 3, 5}) {
                 if ( ! micro && cut != 3) continue;
                 plan::Options o;
                 o.max_tile_leaves = tile; o.micro = micro != 0; o.micro_cut = cut;
+                o.micro_cut2 = cut == 2 ? 2 : (cut == 5 ? 3 : 0);
                 std::snprintf(ctx, sizeof(ctx), "nc %d P %d pseudorandom %d imbalanced %d tile %d micro %d cut %d",
                               nc, P, pr, imb, tile, micro, cut);
                 check(t, nc, P, o, ctx);
