@@ -10,6 +10,7 @@
 #define COMPOSE_AMD_CEDR_MPI_HPP
 
 #include <memory>
+#include <utility>
 
 #include "cedr.hpp"
 
@@ -22,6 +23,9 @@ namespace mpi {
 // (or ordered with respect to) 'stream' and returns 0 on success.
 struct Comm {
   virtual ~Comm () {}
+  // The communicator of the transport underneath, if it has one an adapter can hand back
+  // (cedr_mpi_adapter.hpp: the address of the MPI_Comm); nullptr otherwise.
+  virtual const void* native_handle () const { return nullptr; }
   virtual int rank () const = 0;
   virtual int size () const = 0;
   // recv[r*count : (r+1)*count] = rank r's send[0:count], for every r.
@@ -30,12 +34,29 @@ struct Comm {
   virtual int allreduce_sum (const Real* send, Real* recv, size_t count, hipStream_t stream) = 0;
 };
 
+// What Parallel::comm() returns: the Comm of this build, usable as the shared_ptr it is -- and,
+// when an adapter for a native communicator type is in scope (cedr_mpi_adapter.hpp defines
+// NativeComm<MPI_Comm>), convertible to that type, so that reference-style code such as
+// `MPI_Comm c = p->comm();` or `MPI_Barrier(p->comm())` (cedr/cedr_mpi.hpp:22) compiles unchanged.
+template <typename T> struct NativeComm;  // specialised by adapters: static T get(const Comm&)
+class CommRef {
+  const std::shared_ptr<Comm>& c_;
+public:
+  explicit CommRef (const std::shared_ptr<Comm>& c) : c_(c) {}
+  Comm* operator-> () const { return c_.get(); }
+  Comm& operator* () const { return *c_; }
+  operator const std::shared_ptr<Comm>& () const { return c_; }
+  const std::shared_ptr<Comm>& ptr () const { return c_; }
+  template <typename T, typename = decltype(NativeComm<T>::get(std::declval<const Comm&>()))>
+  operator T () const { return NativeComm<T>::get(*c_); }
+};
+
 class Parallel {
   std::shared_ptr<Comm> comm_;
 public:
   typedef std::shared_ptr<Parallel> Ptr;
   explicit Parallel (const std::shared_ptr<Comm>& comm) : comm_(comm) {}
-  const std::shared_ptr<Comm>& comm () const { return comm_; }
+  CommRef comm () const { return CommRef(comm_); }
   Int size () const { return comm_->size(); }
   Int rank () const { return comm_->rank(); }
   Int root () const { return 0; }

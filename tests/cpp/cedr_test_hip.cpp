@@ -165,6 +165,17 @@ static void bind (cedr::qlt::QLT<>& q, Real* const* d) { q.bind_arrays(d[0], d[1
 static void bind (cedr::caas::CAAS<>& c, Real* const* d) { c.bind_arrays(d[1], d[2], d[3], d[4]); }
 static const Real* result_of (cedr::qlt::QLT<>&, Real* const* d) { return d[5]; }
 static const Real* result_of (cedr::caas::CAAS<>&, Real* const* d) { return d[1]; }
+// The bulk pack / unpack kernels (QLT only: CAAS's layout coincides with the caller's arrays, its bulk
+// form is a plain copy). Returns false if the CDR has none.
+static bool run_bulk (cedr::qlt::QLT<>& q, Real* const* d, Real* out) {
+  q.bind_arrays(nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+  q.set_rhom_bulk(d[0]);
+  q.set_Qm_bulk(d[1], d[2], d[3], d[4]);
+  q.run();
+  q.get_Qm_bulk(out);
+  return true;
+}
+static bool run_bulk (cedr::caas::CAAS<>&, Real* const*, Real*) { return false; }
 
 template <typename CDRT>
 static int drive (const char* name, CDRT& cdr, const std::vector<Tracer>& ts, int n, bool external_memory,
@@ -202,6 +213,21 @@ static int drive (const char* name, CDRT& cdr, const std::vector<Tracer>& ts, in
   std::vector<Real> out((size_t) n*nt);
   HIP_OK(hipMemcpy(out.data(), d[5], N, hipMemcpyDeviceToHost));
   int nzc = 0;
+  {  // the bulk pack / unpack path must reproduce the inline-DeviceOp result bit for bit
+    Real* ob = nullptr;
+    HIP_OK(hipMalloc((void**) &ob, N));
+    HIP_OK(hipMemset(ob, 0, N));
+    if (run_bulk(cdr, d, ob)) {
+      HIP_OK(hipDeviceSynchronize());
+      std::vector<Real> bk((size_t) n*nt);
+      HIP_OK(hipMemcpy(bk.data(), ob, N, hipMemcpyDeviceToHost));
+      int nb = 0;
+      for (size_t i = 0; i < bk.size(); ++i) if (std::memcmp(&bk[i], &out[i], sizeof(Real))) ++nb;
+      if (nb) std::printf("FAIL %s: the bulk path differs from the DeviceOp path in %d values\n", name, nb);
+      nzc += nb;
+    }
+    (void) hipFree(ob);
+  }
   {  // zero-copy mode on the same arrays must reproduce the DeviceOp-driven result exactly
     HIP_OK(hipMemset(d[5], 0, N));
     bind(cdr, d);
