@@ -41,13 +41,14 @@ def parse():
     ap.add_argument("--ncells", type=int, default=1500000)
     ap.add_argument("--ntracers", type=int, default=40)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-cells", type=int, default=750000,
-                    help="cells of the bounded CPU-baseline sample (same tracer count)")
+    ap.add_argument("--cpu-cells", type=int, default=0,
+                    help="cells of the CPU-baseline run (same tracer count); 0 = the configuration itself")
     ap.add_argument("--check", action="store_true", help="verify properties of the results")
     ap.add_argument("--overlap", action="store_true",
-                    help="N = 1 only: QLT and CAAS on two concurrent streams instead of back to back on one "
-                         "(measured: within 2 %% of the one-stream step). With N > 1 the two CDRs share one "
-                         "communicator and one stream, so their collectives are strictly ordered.")
+                    help="QLT and CAAS on two concurrent streams instead of back to back on one (measured on "
+                         "one GPU: 2 %% at 1.5M cells, 10 %% at the 187.5k-cell shard of an 8-GPU run). With N > 1 "
+                         "the two CDRs still share ONE communicator, whose collectives the library orders "
+                         "with events across streams; the default for N > 1 stays one stream.")
     ap.add_argument("--serial", action="store_true", help="(default now; kept for older command lines)")
     ap.add_argument("--comm", choices=["rccl", "gloo"], default="rccl",
                     help="data-path transport for N > 1: the library's RCCL communicator (default) or, "
@@ -94,9 +95,11 @@ def gen_inputs(torch, n, nt, seed, device):
     return rhom, Qm.contiguous(), Qm_min.contiguous(), Qm_max.contiguous(), Qm_prev.contiguous()
 
 
-def cpu_baseline(ncells, nt, nrep_qlt=6, nrep_caas=10):
-    """The oracle (CPU port of the reference algorithm) timed on this host: the
-    reported CPU baseline, never the thing measured as `value`."""
+def cpu_baseline(ncells, nt):
+    """The oracle (CPU port of the reference algorithm, built -O3 -ffp-contract=off) timed on this
+    host on the metric's own configuration: the reported CPU baseline, never the thing measured as
+    `value`. One thread (the reference's Kokkos-Serial shape) and the box's CPU share (OpenMP over
+    level nodes / tracers, as cedr_qlt.cpp:391-393,570-572 and cedr_caas.cpp:187)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as o
     rng = np.random.default_rng(12345)
@@ -110,21 +113,32 @@ def cpu_baseline(ncells, nt, nrep_qlt=6, nrep_caas=10):
     Qm = np.empty_like(Qm_prev)
     for t in range(nt):
         Qm[t] = Qm_prev[t][rng.permutation(ncells)]
-    nthr = min(o.lib().or_max_threads(), 16)  # the GPU box share of host cores for one GPU
+    # threads for the parallel leg: the CPUs this process may use, at most the GPU box's share of
+    # host cores for one GPU (16)
+    try:
+        allowed = len(os.sched_getaffinity(0))
+    except AttributeError:
+        allowed = os.cpu_count() or 1
+    nthr = max(1, min(o.lib().or_max_threads(), allowed, 16))
     tree = o.Tree.make_1d(ncells)
     qlt = o.OracleQLT(tree, ncells)
     qlt.declare([CST] * nt)
     qlt.set(0, rhom, Qm, Qm_min, Qm_max, Qm_prev)
     caas = o.OracleCAAS([ncells], [CST] * nt)
     caas.set(0, rhom, Qm, Qm_min, Qm_max, Qm_prev)
+    # repetitions sized for ~10-20 s of CPU work in all at 1.5M x 40 (one serial QLT run is ~4 s)
+    scale = max(1, int(1500000 * 40 / max(1, ncells * nt)))
+    reps = {"1": (1 * scale, 3 * scale), "all": (3 * scale, 10 * scale)}
     res = {}
     for label, threads in (("1", 1), ("all", nthr)):
         qlt.set_threads(threads)
         caas.set_threads(threads)
-        qlt.run()  # warm-up
-        tq = qlt.time_run(nrep_qlt) / nrep_qlt
-        tc = caas.time_run(Qm, nrep_caas) / nrep_caas
-        res[label] = dict(threads=threads, qlt_s=tq, caas_s=tc,
+        if label == "all":
+            qlt.run()  # warm-up of the thread team
+        nq, nc = reps[label]
+        tq = qlt.time_run(nq) / nq
+        tc = caas.time_run(Qm, nc) / nc
+        res[label] = dict(threads=threads, qlt_s=tq, caas_s=tc, qlt_runs=nq, caas_runs=nc,
                           value=2.0 * ncells * nt / (tq + tc),
                           qlt_updates_per_s=ncells * nt / tq, caas_updates_per_s=ncells * nt / tc)
         if nthr == 1:
@@ -196,9 +210,6 @@ def main():
     if local_rank >= torch.cuda.device_count():
         raise SystemExit("rank %d: no GPU %d on this node (%d visible); --gpus must not exceed the GPU count"
                          % (rank, local_rank, torch.cuda.device_count()))
-    if a.overlap and world > 1:
-        raise SystemExit("--overlap is for N = 1: concurrent collectives of two communicators on one "
-                         "device have no forward-progress guarantee")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     torch.zeros(1, device=device)  # initialise the HIP context before the library is used
@@ -274,7 +285,8 @@ def main():
                     print("bench.py: RCCL transport failed: %s" % next(e for e in errs if e), file=sys.stderr)
                 dist.destroy_process_group()
                 sys.exit(3)
-            transport = "rccl: one communicator of %d ranks, one stream, collectives in program order" % world
+            transport = ("rccl: one communicator of %d ranks, %s, collectives in program order"
+                         % (world, "two streams (event ordered)" if a.overlap else "one stream"))
         else:
             par = par2 = host_staged()
             qlt, caas = make_cdrs(par, par2)
@@ -293,7 +305,7 @@ def main():
     torch.cuda.synchronize()
     # Default: QLT::run then CAAS::run on one stream. --overlap (N = 1): each CDR on its own stream.
     streams = None
-    if a.overlap and world == 1:
+    if a.overlap:
         streams = (torch.cuda.Stream(device=device), torch.cuda.Stream(device=device))
         qlt.set_stream(streams[0].cuda_stream)
         caas.set_stream(streams[1].cuda_stream)
@@ -449,11 +461,17 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         try:
-            res, nthr = cpu_baseline(a.cpu_cells, nt)
+            cc = a.cpu_cells or ncells
+            res, nthr = cpu_baseline(cc, nt)
             cpu = dict(value=res["all"]["value"], unit="cell-tracer-updates/s", cores=res["all"]["threads"],
                        kind="port",
-                       sample="oracle (CPU port of the reference algorithm, OpenMP over level nodes / "
-                              "tracers) QLT+CAAS on %d cells x %d cst tracers" % (a.cpu_cells, nt),
+                       sample="oracle (CPU port of the reference algorithm, g++ -O3 -ffp-contract=off, OpenMP "
+                              "over level nodes / tracers) QLT::run + CAAS::run on %d cells x %d cst tracers%s: "
+                              "%d + %d runs on %d threads (this box's CPU share for one GPU; the host reports "
+                              "%d CPUs), and %d + %d runs on 1 thread (single_thread)"
+                              % (cc, nt, "" if cc == ncells else " (a sample of the %d-cell configuration)" % ncells,
+                                 res["all"]["qlt_runs"], res["all"]["caas_runs"], nthr, os.cpu_count() or 0,
+                                 res["1"]["qlt_runs"], res["1"]["caas_runs"]),
                        host_cores=os.cpu_count(), single_thread=res["1"], all_threads=res["all"])
         except Exception as e:  # the baseline must never take the bench down
             cpu = dict(value=None, unit="cell-tracer-updates/s", cores=0, kind="port",

@@ -90,6 +90,7 @@ _SIGS = {
     "cedr_qlt_declare_tracer": (C.c_int, [_vp, C.c_int, C.c_int]),
     "cedr_qlt_end_tracer_declarations": (C.c_int, [_vp]),
     "cedr_qlt_get_buffers_sizes": (C.c_int, [_vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "cedr_qlt_get_buffers_sizes_tight": (C.c_int, [_vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "cedr_qlt_set_buffers": (C.c_int, [_vp, _vp, _vp]),
     "cedr_qlt_finish_setup": (C.c_int, [_vp]),
     "cedr_qlt_get_problem_type": (C.c_int, [_vp, C.c_int]),
@@ -140,6 +141,9 @@ _SIGS = {
     "cedr_memcpy_h2d": (C.c_int, [_vp, _vp, C.c_size_t]),
     "cedr_memcpy_d2h": (C.c_int, [_vp, _vp, C.c_size_t]),
     "cedr_memcpy_d2d_async": (C.c_int, [_vp, _vp, C.c_size_t, _vp]),
+    "cedr_stream_synchronize": (C.c_int, [C.c_void_p]),
+    "cedr_memcpy_h2d_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "cedr_memcpy_d2h_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "cedr_device_synchronize": (C.c_int, []),
     # kernel level (layer K) entry points used directly by tests / bench
     "cedr_hip_caas_nchunks": (C.c_int32, [C.c_int32]),
@@ -196,15 +200,30 @@ def device_count():
     return lib().cedr_device_count()
 
 
-def _ptr(x):
-    """Device pointer of a DeviceArray, torch tensor, int or None."""
+def _ptr(x, need=None):
+    """Device pointer of a DeviceArray, torch tensor, int or None. Arrays are checked before their
+    address is handed to a kernel: 8-byte elements (float64), contiguous, on the GPU, and at least
+    'need' elements long -- a float32, strided, host or short array would otherwise be silent
+    corruption or a GPU fault."""
     if x is None:
         return None
     if isinstance(x, DeviceArray):
+        if x.dtype.itemsize != 8:
+            raise CedrError("expected an array of doubles, got %s" % x.dtype)
+        if need is not None and x.n < need:
+            raise CedrError("device array has %d elements, %d are needed" % (x.n, need))
         return x.ptr
     if isinstance(x, int):
         return x
     if hasattr(x, "data_ptr"):
+        if str(getattr(x, "dtype", "")) not in ("torch.float64", "float64"):
+            raise CedrError("expected a float64 tensor, got %s" % getattr(x, "dtype", None))
+        if hasattr(x, "is_contiguous") and not x.is_contiguous():
+            raise CedrError("expected a contiguous tensor")
+        if hasattr(x, "is_cuda") and not x.is_cuda:
+            raise CedrError("expected a tensor on the GPU")
+        if need is not None and x.numel() < need:
+            raise CedrError("tensor has %d elements, %d are needed" % (x.numel(), need))
         return x.data_ptr()
     raise TypeError("expected a device array, got %r" % type(x))
 
@@ -328,20 +347,20 @@ class Parallel:
         allgather_host(send[count]) -> recv[size*count]; allreduce_host(send[count]) -> recv[count]."""
         L = lib()
 
-        def ag(s, r, n, st):
-            a = np.empty(n)
-            _chk(L.cedr_memcpy_d2h(a.ctypes.data, s, a.nbytes), "d2h")
-            out = np.ascontiguousarray(allgather_host(a), np.float64)
-            _chk(L.cedr_memcpy_h2d(r, out.ctypes.data, out.nbytes), "h2d")
-            return 0
-
-        def ar(s, r, n, st):
-            a = np.empty(n)
-            _chk(L.cedr_memcpy_d2h(a.ctypes.data, s, a.nbytes), "d2h")
-            out = np.ascontiguousarray(allreduce_host(a), np.float64)
-            _chk(L.cedr_memcpy_h2d(r, out.ctypes.data, out.nbytes), "h2d")
-            return 0
-        return Parallel.callbacks(rank, size, ag, ar)
+        def staged(host_op):
+            # Everything on the stream the library hands over ('st' may be a non-blocking stream that
+            # the null stream does not synchronise with): the send buffer was filled by kernels on st,
+            # and the kernels that read recv follow on st.
+            def f(s, r, n, st):
+                a = np.empty(n)
+                _chk(L.cedr_memcpy_d2h_async(a.ctypes.data, s, a.nbytes, st), "d2h")
+                _chk(L.cedr_stream_synchronize(st), "sync")
+                out = np.ascontiguousarray(host_op(a), np.float64)
+                _chk(L.cedr_memcpy_h2d_async(r, out.ctypes.data, out.nbytes, st), "h2d")
+                _chk(L.cedr_stream_synchronize(st), "sync")  # 'out' must outlive the copy
+                return 0
+            return f
+        return Parallel.callbacks(rank, size, staged(allgather_host), staged(allreduce_host))
 
     def rank(self):
         return lib().cedr_parallel_rank(self.h)
@@ -505,7 +524,9 @@ class _CDR:
         _chk(self._f("run")(self.h), "run")
 
     def set_stream(self, stream):
+        """hipStream_t (int / None) run() and the bulk set_* / get_Qm calls are enqueued on."""
         _chk(self._f("set_stream")(self.h, stream), "set_stream")
+        self._stream = stream
 
 
 class QLT(_CDR):
@@ -531,6 +552,12 @@ class QLT(_CDR):
             raise CedrError(_err())
         return rc
 
+    def get_buffers_sizes_tight(self):
+        """What this build touches (doubles): enough for set_buffers, about half of get_buffers_sizes."""
+        b1, b2 = C.c_size_t(), C.c_size_t()
+        _chk(lib().cedr_qlt_get_buffers_sizes_tight(self.h, C.byref(b1), C.byref(b2)), "get_buffers_sizes_tight")
+        return b1.value, b2.value
+
     def get_device_op(self):
         op = _QltDeviceOp()
         lib().cedr_qlt_get_device_op(self.h, C.byref(op))
@@ -538,22 +565,25 @@ class QLT(_CDR):
 
     def set_rhom(self, rhom):
         """Bulk DeviceOp::set_rhom over all local cells; rhom is a device array [cell]."""
-        _chk(lib().cedr_qlt_set_rhom_bulk(self.h, _ptr(rhom)), "set_rhom")
+        _chk(lib().cedr_qlt_set_rhom_bulk(self.h, _ptr(rhom, self.nlclcells())), "set_rhom")
 
     def set_Qm(self, Qm, Qm_min, Qm_max, Qm_prev):
         """Bulk DeviceOp::set_Qm; device arrays [tracer][cell] in caller tracer order."""
-        _chk(lib().cedr_qlt_set_Qm_bulk(self.h, _ptr(Qm), _ptr(Qm_min), _ptr(Qm_max), _ptr(Qm_prev)),
+        n = self.nlclcells() * self.get_num_tracers()
+        _chk(lib().cedr_qlt_set_Qm_bulk(self.h, _ptr(Qm, n), _ptr(Qm_min, n), _ptr(Qm_max, n), _ptr(Qm_prev, n)),
              "set_Qm")
 
     def get_Qm(self, out):
-        _chk(lib().cedr_qlt_get_Qm_bulk(self.h, _ptr(out)), "get_Qm")
+        _chk(lib().cedr_qlt_get_Qm_bulk(self.h, _ptr(out, self.nlclcells() * self.get_num_tracers())), "get_Qm")
 
     def bind_arrays(self, rhom, Qm, Qm_min, Qm_max, Qm_prev, Qm_out):
         """Zero-copy mode: run() reads the caller's device arrays (rhom[cell]; the others
         [tracer][cell]) and writes the limited masses to Qm_out (may be Qm). rhom=None switches back."""
-        f = lambda x: _ptr(x) if x is not None else None
-        _chk(lib().cedr_qlt_bind_arrays(self.h, f(rhom), f(Qm), f(Qm_min), f(Qm_max), f(Qm_prev), f(Qm_out)),
-             "bind_arrays")
+        nc = self.nlclcells()
+        n = nc * self.get_num_tracers()
+        f = lambda x, k: _ptr(x, k) if x is not None else None
+        _chk(lib().cedr_qlt_bind_arrays(self.h, f(rhom, nc), f(Qm, n), f(Qm_min, n), f(Qm_max, n), f(Qm_prev, n),
+                                        f(Qm_out, n)), "bind_arrays")
 
     def metadata(self):
         nt = self.get_num_tracers()
@@ -614,7 +644,8 @@ class CAAS(_CDR):
     def _copy(self, row0, src, nrows):
         op = self.get_device_op()
         nbytes = 8 * self.n * nrows
-        _chk(lib().cedr_memcpy_d2d_async(op.d + 8 * self.n * row0, _ptr(src), nbytes, None), "copy")
+        _chk(lib().cedr_memcpy_d2d_async(op.d + 8 * self.n * row0, _ptr(src), nbytes,
+                                         getattr(self, "_stream", None)), "copy")
 
     def set_rhom(self, rhom):
         """Bulk DeviceOp::set_rhom (cedr_caas_inl.hpp:14-19)."""
@@ -634,7 +665,8 @@ class CAAS(_CDR):
 
     def get_Qm(self, out):
         op = self.get_device_op()
-        _chk(lib().cedr_memcpy_d2d_async(_ptr(out), op.d + 8 * self.n, 8 * self.n * op.nt, None))
+        _chk(lib().cedr_memcpy_d2d_async(_ptr(out), op.d + 8 * self.n, 8 * self.n * op.nt,
+                                         getattr(self, "_stream", None)))
 
     def recv_ptr(self):
         p = _vp()

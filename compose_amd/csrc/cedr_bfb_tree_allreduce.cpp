@@ -1,5 +1,8 @@
 #include "cedr_bfb_tree_allreduce.hpp"
 
+#include <memory>
+#include <vector>
+
 #include <hip/hip_runtime.h>
 
 #include "../../include/cedr_hip.h"
@@ -22,8 +25,11 @@ struct BfbTreeAllReducerHip::Impl {
   // Transposed sends (field, leaf) whose leaf order is the slot order are swept in place:
   // the first stage reads send's rows through a row table instead of a scattered copy.
   bool identity = false;             // local leaf id == slot
-  dev::Buffer<const Real*> rows;     // [nfield] row pointers into the last send seen
-  const Real* rows_for = nullptr;
+  // [nfield] row pointers into a send buffer, one table per buffer seen (callers alternate between a
+  // few buffers; a table is built once, the first time its buffer shows up: no host stall afterwards)
+  struct RowTable { const Real* send = nullptr; std::unique_ptr<dev::Buffer<const Real*> > rows; };
+  std::vector<RowTable> tables;
+  size_t next_evict = 0;
 };
 
 void BfbTreeAllReducerHip::init (const mpi::Parallel::Ptr& p, const tree::FlatTree& tree,
@@ -77,14 +83,24 @@ void BfbTreeAllReducerHip::allreduce (const Real* send, Real* recv, const bool t
   const int64_t S = eng_->stride();
   const Real* const* in_rows = nullptr;
   if (transpose && m_->identity && eng_->first_stage_takes_rows()) {
-    if (m_->rows_for != send) {  // (re)build the row table: rows of 'send' are nlocal apart
+    Impl::RowTable* tab = nullptr;
+    for (auto& t : m_->tables) if (t.send == send) tab = &t;
+    if ( ! tab) {  // first time this buffer is seen: rows of 'send' are nlocal apart
       std::vector<const Real*> r(nfield_);
       for (Int f = 0; f < nfield_; ++f) r[f] = send + static_cast<size_t>(f)*nlocal_;
-      cedr_hip_check(hipStreamSynchronize(s));  // a sweep still reading the old table?
-      m_->rows.upload(r);
-      m_->rows_for = send;
+      constexpr size_t kMaxTables = 8;
+      if (m_->tables.size() < kMaxTables) {
+        m_->tables.emplace_back();
+        tab = &m_->tables.back();
+      } else {  // recycle the oldest table; a sweep may still be reading it
+        tab = &m_->tables[m_->next_evict++ % kMaxTables];
+        cedr_hip_check(hipStreamSynchronize(s));
+      }
+      tab->rows.reset(new dev::Buffer<const Real*>());
+      tab->rows->upload(r);
+      tab->send = send;
     }
-    in_rows = m_->rows.data();
+    in_rows = tab->rows->data();
   } else if (transpose) {
     cedr_k_check(cedr_hip_scatter_slots_fm(bd, S, nfield_, m_->leaf_slots.data(), nlocal_, send, s));
   } else {

@@ -169,6 +169,9 @@ int cedr_qlt_end_tracer_declarations (void* h) {
 int cedr_qlt_get_buffers_sizes (void* h, size_t* b1, size_t* b2) {
   CEDR_TRY Q(h).get_buffers_sizes(*b1, *b2); return 0; CEDR_CATCH(-1)
 }
+int cedr_qlt_get_buffers_sizes_tight (void* h, size_t* b1, size_t* b2) {
+  CEDR_TRY Q(h).get_buffers_sizes_tight(*b1, *b2); return 0; CEDR_CATCH(-1)
+}
 int cedr_qlt_set_buffers (void* h, double* b1, double* b2) {
   CEDR_TRY Q(h).set_buffers(b1, b2); return 0; CEDR_CATCH(-1)
 }
@@ -402,5 +405,12 @@ int cedr_memcpy_d2d_async (void* d, const void* s, size_t n, cedr_stream_t st) {
   return static_cast<int>(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, st));
 }
 int cedr_device_synchronize (void) { return static_cast<int>(hipDeviceSynchronize()); }
+int cedr_stream_synchronize (cedr_stream_t st) { return static_cast<int>(hipStreamSynchronize(st)); }
+int cedr_memcpy_h2d_async (void* d, const void* s, size_t n, cedr_stream_t st) {
+  return static_cast<int>(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, st));
+}
+int cedr_memcpy_d2h_async (void* d, const void* s, size_t n, cedr_stream_t st) {
+  return static_cast<int>(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, st));
+}
 
 }  // extern "C"

@@ -69,6 +69,22 @@ const RcclApi& rccl () {
 struct RcclComm : public Comm {
   ncclComm_t comm_;
   int rank_, size_;
+  // Collectives of ONE communicator must execute in the same order on every rank. Callers issue
+  // them in program order, but possibly on different streams (QLT and CAAS each on its own): every
+  // collective therefore waits for the previous one's completion event when the stream changes,
+  // so the order of execution is the order of issue whatever the streams are.
+  hipEvent_t done_ = nullptr;
+  hipStream_t last_ = nullptr;
+  bool used_ = false;
+  void order_before (hipStream_t s) {
+    if (used_ && s != last_) (void) hipStreamWaitEvent(s, done_, 0);
+  }
+  void order_after (hipStream_t s) {
+    if ( ! done_) (void) hipEventCreateWithFlags(&done_, hipEventDisableTiming);
+    (void) hipEventRecord(done_, s);
+    last_ = s;
+    used_ = true;
+  }
   RcclComm (const void* id, int rank, int size) : comm_(nullptr), rank_(rank), size_(size) {
     const RcclApi& a = rccl();
     cedr_throw_if( ! a.ok, "librccl could not be loaded");
@@ -77,14 +93,23 @@ struct RcclComm : public Comm {
     const int e = a.CommInitRank(&comm_, size, blob, rank);
     cedr_throw_if(e != kNcclSuccess, "ncclCommInitRank returned " << e);
   }
-  ~RcclComm () override { if (comm_) rccl().CommDestroy(comm_); }
+  ~RcclComm () override {
+    if (comm_) rccl().CommDestroy(comm_);
+    if (done_) (void) hipEventDestroy(done_);
+  }
   int rank () const override { return rank_; }
   int size () const override { return size_; }
   int allgather (const Real* send, Real* recv, size_t count, hipStream_t s) override {
-    return rccl().AllGather(send, recv, count, kNcclFloat64, comm_, s);
+    order_before(s);
+    const int e = rccl().AllGather(send, recv, count, kNcclFloat64, comm_, s);
+    order_after(s);
+    return e;
   }
   int allreduce_sum (const Real* send, Real* recv, size_t count, hipStream_t s) override {
-    return rccl().AllReduce(send, recv, count, kNcclFloat64, kNcclSum, comm_, s);
+    order_before(s);
+    const int e = rccl().AllReduce(send, recv, count, kNcclFloat64, kNcclSum, comm_, s);
+    order_after(s);
+    return e;
   }
 };
 

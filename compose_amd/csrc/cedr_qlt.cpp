@@ -190,6 +190,13 @@ void QLTHip::get_buffers_sizes (size_t& buf1, size_t& buf2) {
   buf2 = md_.prob2br2l[MetaData::nprobtypes]*nslots;
 }
 
+void QLTHip::get_buffers_sizes_tight (size_t& buf1, size_t& buf2) {
+  cedr_throw_if(mdb_ != nullptr, "call end_tracer_declarations first");
+  const size_t stride = static_cast<size_t>(eng_->stride());
+  buf1 = md_.prob2bl2r[MetaData::nprobtypes]*stride;
+  buf2 = md_.prob2br2l[MetaData::nprobtypes]*stride;
+}
+
 void QLTHip::set_buffers (Real* buf1, Real* buf2) {
   d_->l2r = buf1;
   d_->r2l = buf2;
@@ -280,6 +287,10 @@ void QLTHip::set_rhom_bulk (const Real* rhom) {
 void QLTHip::set_Qm_bulk (const Real* Qm, const Real* Qm_min, const Real* Qm_max,
                           const Real* Qm_prev) {
   cedr_throw_if( ! o.l2r_data, "finish_setup was not called");
+  cedr_throw_if( ! Qm || ! Qm_min || ! Qm_max, "set_Qm_bulk: null array");
+  if ( ! Qm_prev)  // the kernel would dereference it (the inline DeviceOp traps: cedr_qlt_inl.hpp:53-54)
+    for (const Int pt : md_.trcr2prob)
+      cedr_throw_if(pt & ProblemType::conserve, "set_Qm_bulk: Qm_prev was not provided but a tracer conserves");
   cedr_k_check(cedr_hip_qlt_set_Qm(get_num_tracers(), o.trcr2prob, o.trcr2bl2r, o.stride,
                                    nlclcells(), Qm, Qm_min, Qm_max, Qm_prev, o.l2r_data,
                                    d_->stream));

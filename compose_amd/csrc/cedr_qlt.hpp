@@ -63,6 +63,10 @@ public:
   void declare_tracer(int problem_type, const Int& rhomidx) override;
   void end_tracer_declarations() override;
   void get_buffers_sizes(size_t& buf1, size_t& buf2) override;
+  // What this build really touches: ndps * stride Reals per buffer, about half of the reference's
+  // figure above (internal tree nodes other than tile outputs never reach HBM here). A caller that
+  // brings its own memory may size it by this instead; set_buffers accepts either.
+  void get_buffers_sizes_tight(size_t& buf1, size_t& buf2);
   void set_buffers(Real* buf1, Real* buf2) override;
   void finish_setup() override;
   int get_problem_type(const Int& tracer_idx) const override;

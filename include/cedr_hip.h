@@ -243,6 +243,9 @@ void cedr_qlt_free(void* qlt);
 int cedr_qlt_declare_tracer(void* qlt, int problem_type, int rhomidx);
 int cedr_qlt_end_tracer_declarations(void* qlt);
 int cedr_qlt_get_buffers_sizes(void* qlt, size_t* buf1, size_t* buf2); /* in doubles */
+/* What this build touches (ndps * stride doubles, about half of the reference's figure above):
+ * enough for set_buffers; the reference-sized query stays for callers written against it. */
+int cedr_qlt_get_buffers_sizes_tight(void* qlt, size_t* buf1, size_t* buf2);
 int cedr_qlt_set_buffers(void* qlt, double* buf1, double* buf2);       /* device memory */
 int cedr_qlt_finish_setup(void* qlt);
 int cedr_qlt_get_problem_type(void* qlt, int tracer_idx); /* < 0 on error */
@@ -357,6 +360,11 @@ int cedr_memcpy_h2d(void* dst, const void* src, size_t bytes);
 int cedr_memcpy_d2h(void* dst, const void* src, size_t bytes);
 int cedr_memcpy_d2d_async(void* dst, const void* src, size_t bytes, cedr_stream_t stream);
 int cedr_device_synchronize(void);
+/* Stream-ordered forms: a host application that stages a collective through host memory must work
+ * on the stream it is handed (cedr_allgather_fn / cedr_allreduce_sum_fn), not on the null stream. */
+int cedr_stream_synchronize(cedr_stream_t stream);
+int cedr_memcpy_h2d_async(void* dst, const void* src, size_t bytes, cedr_stream_t stream);
+int cedr_memcpy_d2h_async(void* dst, const void* src, size_t bytes, cedr_stream_t stream);
 
 #ifdef __cplusplus
 }

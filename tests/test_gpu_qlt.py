@@ -188,3 +188,51 @@ def test_qlt_caller_trees_bitwise(gpu, oracle, kind, nleaf):
     # caterpillar accumulates more roundoff in the reference algorithm itself)
     if kind == "merge":
         assert R.check(trs, v, got, False, verbose=False)[0] == 0
+
+
+def test_array_arguments_are_validated(gpu):
+    """A wrong element type, a short array or a missing Qm_prev is an error message, never a kernel
+    reading the wrong bytes (the inline DeviceOp traps on a missing Qm_prev: cedr_qlt_inl.hpp:53-54)."""
+    ca = gpu
+    n, types = 100, [7, 2]
+    q = common.make_hip_qlt(ca, ca.Tree.make_1d(n), n, types)
+    d = ca.DeviceArray(n * len(types))
+    with pytest.raises(ca.CedrError):
+        q.set_Qm(d, d, d, None)                      # tracer 0 conserves
+    with pytest.raises(ca.CedrError):
+        q.set_Qm(d, d, ca.DeviceArray(n), d)         # too short
+    with pytest.raises(ca.CedrError):
+        q.set_rhom(ca.DeviceArray(n, np.int32))      # not doubles
+    try:
+        import torch
+    except ImportError:
+        return
+    dev = torch.device("cuda", 0)
+    with pytest.raises(ca.CedrError):
+        q.set_rhom(torch.zeros(n, dtype=torch.float32, device=dev))
+    with pytest.raises(ca.CedrError):
+        q.set_rhom(torch.zeros(n, dtype=torch.float64))  # host tensor
+    with pytest.raises(ca.CedrError):
+        q.set_rhom(torch.zeros(2 * n, dtype=torch.float64, device=dev)[::2])  # strided
+
+
+def test_tight_buffers(gpu, oracle):
+    """set_buffers with the TIGHT sizes (what this build touches, about half of the reference's
+    figure) gives the same bits as library-owned memory."""
+    ca = gpu
+    n = 3000
+    trs = R.tracers_vector()[:12]
+    types = [t.problem_type for t in trs]
+    v = R.make_values(trs, n, seed=11)
+    q = ca.QLT(ca.Parallel.self_(), n, ca.Tree.make_1d(n))
+    for t in types:
+        q.declare_tracer(t, 0)
+    q.end_tracer_declarations()
+    b1, b2 = q.get_buffers_sizes()
+    t1, t2 = q.get_buffers_sizes_tight()
+    assert t1 < 0.6 * b1 and t2 < 0.6 * b2
+    q.set_buffers(ca.DeviceArray(t1), ca.DeviceArray(t2))
+    q.finish_setup()
+    got = common.run_hip_qlt(ca, q, v)
+    want = common.run_oracle_qlt(oracle, (False, False), n, 1, types, v)
+    assert np.array_equal(got, want)
