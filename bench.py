@@ -395,9 +395,9 @@ def main():
             e.update(algorithmic_bytes=alg[(name, aux)], achieved_GBs=gbs, frac=gbs / HBM_PEAK_GBS)
         kernels.append(e)
     # HBM traffic per launch from the PMC counters of a profiling run of this same
-    # command (profiles/r01_traffic.json, made by tools/profile_traffic.sh).
+    # command (profiles/r02_traffic.json, made by tools/profile_traffic.sh).
     try:
-        tr = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+        tr = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
         if world == 1 and tr["config"] == {"ncells": ncells, "ntracers": nt}:
             for k in kernels:
                 t = tr["kernels"].get(k["kernel"])

@@ -15,7 +15,7 @@ src, dst = sys.argv[1], sys.argv[2]
 agg = collections.defaultdict(list)
 for r in csv.DictReader(open(src)):
     m = re.search(r"(\w+_kernel)", r["Kernel_Name"])
-    if not m or not m.group(1).startswith(("qlt_", "tree_up", "caas_", "gather_slots", "scatter_slots",
+    if not m or not m.group(1).startswith(("qlt_", "tree_", "caas_", "gather_slots", "scatter_slots",
                                             "copy_slots")):
         continue
     grid = "%sx%sx%s" % (r["Grid_Size_X"], r["Grid_Size_Y"], r["Grid_Size_Z"])

@@ -12,7 +12,8 @@ import sys
 d = sys.argv[1]
 ncells, nt = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (1500000, 40)
 # rocprof kernel name -> the name bench.py's launch profiler uses, first stage only (largest grid)
-OURS = {"qlt_down_micro_kernel": "qlt_down_kernel", "tree_up_micro_kernel": "tree_up_kernel",
+OURS = {"qlt_down_micro_kernel": "qlt_down_kernel", "qlt_down_sp_kernel": "qlt_down_kernel",
+        "tree_up_micro_kernel": "tree_up_kernel",
         "caas_reduce_kernel": "caas_reduce_kernel", "caas_finish_kernel": "caas_finish_kernel"}
 raw = {}
 for tag in ("FETCH_SIZE", "WRITE_SIZE", "odd_FETCH_SIZE", "odd_WRITE_SIZE"):
