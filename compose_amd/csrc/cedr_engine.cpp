@@ -109,8 +109,8 @@ void TreeEngine::up (int32_t nfields, const uint8_t* op_dev, double* data, bool 
                      hipStream_t stream, const double* const* in_rows) {
   cedr_throw_if( ! uploaded_, "TreeEngine::upload was not called");
   for (size_t i = 0; i < local_.size(); ++i)
-    cedr_k_check(cedr_hip_tree_up_rows(&local_[i]->h, nfields, op_dev, stride_, data,
-                                       i == 0 ? in_rows : nullptr, plan_.nlcl, zero_init, stream));
+    cedr_k_check(cedr_hip_tree_up_rows_sums(&local_[i]->h, nfields, op_dev, stride_, data,
+                                            i == 0 ? in_rows : nullptr, plan_.nlcl, zero_init, all_sums_, stream));
   if (top_.empty()) return;
   exchange(nfields, data, stream);
   cedr_k_check(cedr_hip_scatter_slots(data, stride_, nfields, gather_slots_.data(),
@@ -140,8 +140,8 @@ const double* TreeEngine::up_to_exchange (int32_t nfields, const uint8_t* op_dev
                                           const double* const* in_rows) {
   cedr_throw_if( ! uploaded_ || ! apex_, "up_to_exchange needs an uploaded plan with an apex tile");
   for (size_t i = 0; i < local_.size(); ++i)
-    cedr_k_check(cedr_hip_tree_up_rows(&local_[i]->h, nfields, op_dev, stride_, data,
-                                       i == 0 ? in_rows : nullptr, plan_.nlcl, zero_init, stream));
+    cedr_k_check(cedr_hip_tree_up_rows_sums(&local_[i]->h, nfields, op_dev, stride_, data,
+                                            i == 0 ? in_rows : nullptr, plan_.nlcl, zero_init, all_sums_, stream));
   exchange(nfields, data, stream);
   return recvbuf_.data();
 }

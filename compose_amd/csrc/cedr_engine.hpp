@@ -45,6 +45,8 @@ public:
   // its inputs from in_rows[f][slot] instead of data (zero-copy mode).
   void up(int32_t nfields, const uint8_t* op_dev, double* data, bool zero_init,
           hipStream_t stream, const double* const* in_rows = nullptr);
+  // The owner's promise that every field's combine rule is a plain sum (op_dev all zero).
+  void set_all_sums (bool v) { all_sums_ = v; }
   // Multi-rank runs whose replicated top fits one apex tile (plan::Plan::apex): the leaves->root
   // sweep stops at the exchange -- local stages, gather of this rank's boundary roots, ONE
   // all-gather -- and returns the gathered records [record][nfields] for the apex kernels
@@ -77,6 +79,7 @@ private:
   dev::Buffer<double> sendbuf_, recvbuf_;
   int32_t xfields_ = 0;
   bool uploaded_ = false;
+  bool all_sums_ = false;
 };
 
 }  // namespace engine

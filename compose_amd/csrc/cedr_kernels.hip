@@ -466,7 +466,9 @@ __device__ __forceinline__ double micro_up_sum (const int shape, const double a,
 // ROWS: the tile's INPUT rows come from a table of per-field base pointers
 // (in_rows[f] + slot) instead of data + f*stride + slot -- the caller's own
 // [tracer][cell] arrays in zero-copy mode. Outputs always go to 'data'.
-template <int FT, bool ROWS>
+// SUMS: the caller guarantees that every field's rule is a plain sum and zero_init is 0 (QLT without
+// consistent-only tracers -- E3SM's case): no rule table, no per-field branches in the chunk loop.
+template <int FT, bool ROWS, bool SUMS>
 __global__ __launch_bounds__(kBlock)
 void tree_up_micro_kernel (const cedr_hip_stage st, const int nfields,
                            const uint8_t* __restrict__ op, const int64_t stride,
@@ -556,14 +558,14 @@ void tree_up_micro_kernel (const cedr_hip_stage st, const int nfields,
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
       const int fr = c*FT + wave + kNW*r;
-      const int orow = fr < nfields ? opL[fr] : 0;
+      const int orow = (SUMS || fr >= nfields) ? 0 : opL[fr];
       double wa = cab[r].x, wb = cab[r].y;
       const double wc = ccc[r];
       if (ROWS) {  // window shifted back by cshift: cell a sits at position cshift, b at cshift + 1
         wa = cshift == 0 ? wa : (cshift == 1 ? wb : wc);
         wb = cshift == 0 ? wb : wc;
       }
-      const double val = (orow == 0 && ! zero_init) ?
+      const double val = (SUMS || (orow == 0 && ! zero_init)) ?
         micro_up_sum(m.shape, wa, wb, wc) : micro_up(m.shape, orow, zero_init, wa, wb, wc);
       if (lane < nleaf) v[(wave + kNW*r)*pitch + lane] = val;
     }
@@ -576,7 +578,7 @@ void tree_up_micro_kernel (const cedr_hip_stage st, const int nfields,
     const int rr = lane & (NR - 1);                  // this lane's row among the wave's NR
     double* const vr = v + (wave + kNW*rr)*pitch;
     const int fl = c*FT + wave + kNW*rr;             // its field
-    const int o = fl < nfields ? opL[fl] : 0;
+    const int o = (SUMS || fl >= nfields) ? 0 : opL[fl];
     for (int lv = 0; lv < tile.nlvl; ++lv) {
       wave_lds_order();
       const int a = lvlL[lv];
@@ -584,7 +586,8 @@ void tree_up_micro_kernel (const cedr_hip_stage st, const int nfields,
       for (int q = lane; q < nitems; q += kWave) {
         const int j = a + (q >> LR);
         const uint32_t kk = kidsL[j];
-        vr[nleaf + j] = combine(o, zero_init, vr[kk & 0xffff], vr[kk >> 16]);
+        if (SUMS) vr[nleaf + j] = vr[kk & 0xffff] + vr[kk >> 16];
+        else vr[nleaf + j] = combine(o, zero_init, vr[kk & 0xffff], vr[kk >> 16]);
       }
     }
     wave_lds_order();
@@ -1891,6 +1894,12 @@ int cedr_hip_tree_up (const cedr_hip_stage* st, int32_t nfields, const uint8_t* 
 int cedr_hip_tree_up_rows (const cedr_hip_stage* st, int32_t nfields, const uint8_t* op,
                            int64_t stride, double* data, const double* const* in_rows,
                            int32_t nrow, int zero_init, cedr_stream_t stream) {
+  return cedr_hip_tree_up_rows_sums(st, nfields, op, stride, data, in_rows, nrow, zero_init, 0, stream);
+}
+
+int cedr_hip_tree_up_rows_sums (const cedr_hip_stage* st, int32_t nfields, const uint8_t* op,
+                                int64_t stride, double* data, const double* const* in_rows,
+                                int32_t nrow, int zero_init, int all_sums, cedr_stream_t stream) {
   ProfScope ps(K_TREE_UP, st->ntiles, stream);
   if (st->ntiles == 0 || nfields == 0) return 0;
   if (st->max_nleaf > 256) return static_cast<int>(hipErrorInvalidValue);
@@ -1904,18 +1913,20 @@ int cedr_hip_tree_up_rows (const cedr_hip_stage* st, int32_t nfields, const uint
   if (lds > 160*1024) return static_cast<int>(hipErrorInvalidValue);
   const dim3 grid(st->ntiles, chunk_split(st->ntiles, (nfields + kUpFT - 1)/kUpFT, kSplitUp));
   const dim3 gridx(xcd_grid(st->ntiles), grid.y);  // micro kernels: XCD-contiguous tile ranges
-  if (st->micro && in_rows) {
+  if (st->micro) {
     if (st->max_nleaf > kWave) return static_cast<int>(hipErrorInvalidValue);
-    int e = set_lds_limit(tree_up_micro_kernel<kUpFT, true>, lds);
+    auto go = [&] (auto kernel) -> int {
+      int e = set_lds_limit(kernel, lds);
+      if (e) return e;
+      hipLaunchKernelGGL(kernel, gridx, dim3(kBlock), lds, stream,
+                         *st, nfields, op, stride, data, in_rows, nrow, zero_init, pitch);
+      return 0;
+    };
+    const bool sums = all_sums && ! zero_init;
+    int e;
+    if (in_rows) e = sums ? go(tree_up_micro_kernel<kUpFT, true, true>) : go(tree_up_micro_kernel<kUpFT, true, false>);
+    else e = sums ? go(tree_up_micro_kernel<kUpFT, false, true>) : go(tree_up_micro_kernel<kUpFT, false, false>);
     if (e) return e;
-    hipLaunchKernelGGL((tree_up_micro_kernel<kUpFT, true>), gridx, dim3(kBlock), lds, stream,
-                       *st, nfields, op, stride, data, in_rows, nrow, zero_init, pitch);
-  } else if (st->micro) {
-    if (st->max_nleaf > kWave) return static_cast<int>(hipErrorInvalidValue);
-    int e = set_lds_limit(tree_up_micro_kernel<kUpFT, false>, lds);
-    if (e) return e;
-    hipLaunchKernelGGL((tree_up_micro_kernel<kUpFT, false>), gridx, dim3(kBlock), lds, stream,
-                       *st, nfields, op, stride, data, in_rows, nrow, zero_init, pitch);
   } else if (st->max_nleaf <= 128) {
     int e = set_lds_limit(tree_up_kernel<kUpFT, 2>, lds);
     if (e) return e;

@@ -233,6 +233,9 @@ void QLTHip::finish_setup () {
       }
     }
     d.l2r_op.upload(op);
+    bool sums = true;
+    for (const uint8_t o1 : op) if (o1) sums = false;
+    eng_->set_all_sums(sums);
     o.trcr2prob = d.trcr2prob.data();
     o.trcr2bl2r = d.trcr2bl2r.data();
     o.trcr2br2l = d.trcr2br2l.data();

@@ -88,6 +88,11 @@ int cedr_hip_tree_up(const cedr_hip_stage* stage, int32_t nfields, const uint8_t
 int cedr_hip_tree_up_rows(const cedr_hip_stage* stage, int32_t nfields, const uint8_t* op,
                           int64_t stride, double* data, const double* const* in_rows, int32_t nrow,
                           int zero_init, cedr_stream_t stream);
+/* The same with a promise: all_sums != 0 says every op[f] is 0 (a plain sum), which lets micro
+ * stages run a build without the per-field rule (QLT without consistent-only tracers). */
+int cedr_hip_tree_up_rows_sums(const cedr_hip_stage* stage, int32_t nfields, const uint8_t* op,
+                               int64_t stride, double* data, const double* const* in_rows, int32_t nrow,
+                               int zero_init, int all_sums, cedr_stream_t stream);
 
 /* Root->leaves sweep over one stage: re-forms the tile's node sums in LDS,
  * takes the tile root's assigned mass from r2l, solves every node problem
