@@ -509,19 +509,24 @@ void tree_up_micro_kernel (const cedr_hip_stage st, const int nfields,
   // what enters a result); rows past the last field re-read the last one.
   const double* const plast = src0 + static_cast<size_t>(nfields - 1)*stride;
   // 'staged': the LDS copy of the row table is visible (not yet for the first chunk)
-  auto load = [&] (const int c, d2v (&ab)[NR], double (&cc)[NR], const bool staged) {
+  // 'more' false (no next chunk): the loads still happen -- the count of loads in flight stays
+  // static -- but all from field 0's row, a single row of this tile that is in cache, instead of
+  // re-reading a whole chunk (that was +9 % load traffic through the CU's load path at 11 chunks).
+  auto load = [&] (const int c, d2v (&ab)[NR], double (&cc)[NR], const bool staged, const bool more) {
     if (ROWS) {
 #pragma unroll
       for (int r = 0; r < NR; ++r) {
         int f = c*FT + wave + kNW*r;
         if (f > nfields - 1) f = nfields - 1;
+        if ( ! more) f = 0;
         asm_load_cells(ab[r], cc[r], (staged ? rowsL[f] : in_rows[f]) + cell0);
       }
     } else {
       const double* prow = src0 + static_cast<size_t>(c*FT + wave)*stride;
 #pragma unroll
       for (int r = 0; r < NR; ++r) {
-        asm_load_cells(ab[r], cc[r], prow <= plast ? prow : plast);
+        const double* p = prow <= plast ? prow : plast;
+        asm_load_cells(ab[r], cc[r], more ? p : src0);
         prow += static_cast<size_t>(kNW)*stride;
       }
     }
@@ -534,7 +539,7 @@ void tree_up_micro_kernel (const cedr_hip_stage st, const int nfields,
 #endif
   d2v cab[NR], nab[NR];
   double ccc[NR], ncc[NR];
-  load(blockIdx.y, cab, ccc, false);  // blockIdx.y < nchunks by construction of the grid
+  load(blockIdx.y, cab, ccc, false, true);  // blockIdx.y < nchunks by construction of the grid
   stage_tile_meta(st, tile, kidsL, lvlL);
   if constexpr (FT == 8*kNW) { CEDR_WAIT_VM0_8(cab, ccc); }
   else if constexpr (FT == 4*kNW) { CEDR_WAIT_VM0_4(cab, ccc); }
@@ -546,14 +551,14 @@ void tree_up_micro_kernel (const cedr_hip_stage st, const int nfields,
     const int cn = c + gridDim.y;
 #ifdef CEDR_UP_NOPREFETCH  // experiment: no chunk in flight during the combines
     if (c != static_cast<int>(blockIdx.y)) {
-      load(c, cab, ccc, true);
+      load(c, cab, ccc, true, true);
       if constexpr (FT == 8*kNW) { CEDR_WAIT_VM0_8(cab, ccc); }
       else if constexpr (FT == 4*kNW) { CEDR_WAIT_VM0_4(cab, ccc); }
       else { CEDR_WAIT_VM0_2(cab, ccc); }
     }
     (void) cn;
 #else
-    load(cn < nchunks ? cn : c, nab, ncc, true);  // the last chunk re-reads itself: keeps the count static
+    load(cn < nchunks ? cn : c, nab, ncc, true, cn < nchunks);
 #endif
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
