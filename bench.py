@@ -412,9 +412,14 @@ def main():
                         peak=HBM_PEAK_GBS, unit="GB/s", frac=dom["frac"], traffic=dom.get("traffic"),
                         avg_ms=dom["avg_ms"], algorithmic_bytes_per_launch=dom["algorithmic_bytes"],
                         launch="first stage: %d workgroups (tiles)" % dom["launch"],
-                        rocprof="every stage runs the same *_micro_kernel, so rocprofv3 --stats averages all "
-                                "stages under one name; profiles/*_kernel_stats_by_grid.csv splits the same "
-                                "trace by launch grid (tools/kernel_stats_by_grid.py)")
+                        rocprof="every stage runs the same sweep kernels (qlt_down_sp_kernel / tree_up_micro_kernel),"
+                                " so rocprofv3 --stats averages all stages under one name; "
+                                "profiles/r02_kernel_stats_by_grid.csv splits the same trace by launch grid "
+                                "(tools/kernel_stats_by_grid.py)")
+        if dom["kernel"] == "qlt_down_kernel":
+            roofline["bound_note"] = ("reported against the HBM roofline, the metric's roofline; the measured limiter of "
+                                      "this kernel is fp64 instruction issue: with cache-resident inputs it is as "
+                                      "slow (profiles/r02_down_experiments.md)")
 
     # Pack / unpack either side of run() (reported apart from `value`).
     def timed_sync(fn, reps=5):
