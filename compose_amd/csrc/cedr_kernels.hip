@@ -466,6 +466,10 @@ __device__ __forceinline__ double micro_up_sum (const int shape, const double a,
 // ROWS: the tile's INPUT rows come from a table of per-field base pointers
 // (in_rows[f] + slot) instead of data + f*stride + slot -- the caller's own
 // [tracer][cell] arrays in zero-copy mode. Outputs always go to 'data'.
+// An unoptimised build keeps values in memory between statements: do not leave asm loads in flight there.
+#if ! defined(__OPTIMIZE__) && ! defined(CEDR_UP_NOPREFETCH)
+# define CEDR_UP_NOPREFETCH
+#endif
 // SUMS: the caller guarantees that every field's rule is a plain sum and zero_init is 0 (QLT without
 // consistent-only tracers -- E3SM's case): no rule table, no per-field branches in the chunk loop.
 template <int FT, bool ROWS, bool SUMS>
@@ -1878,7 +1882,13 @@ inline int pitch_for (int n) { return (n + 30)/32*32 + 1; }
 // workgroup per CU slot is enough); the root->leaves kernels are limited by the
 // last, partly idle round of workgroups and prefer ~4 rounds (measured at 187 500
 // cells x 40 tracers, the 8-GPU shard: 0.117 -> 0.103 ms).
-constexpr int kSplitUp = 1024, kSplitDown = 3072;  // kSplitDown: micro tiles only
+constexpr int kSplitUp = 1024, kSplitDownDefault = 3072;  // kSplitDown: micro tiles only
+// (experiments: CEDR_HIP_SPLIT_DOWN overrides the target)
+inline int split_down_target () {
+  static const int v = [] { const char* e = std::getenv("CEDR_HIP_SPLIT_DOWN"); return e ? std::atoi(e) : kSplitDownDefault; }();
+  return v;
+}
+#define kSplitDown split_down_target()
 inline int chunk_split (int ntiles, int nchunks, int target) {
   int y = (target + ntiles - 1)/ntiles;
   if (y > nchunks) y = nchunks;
