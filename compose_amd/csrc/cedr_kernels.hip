@@ -588,7 +588,11 @@ void tree_up_micro_kernel (const cedr_hip_stage st, const int nfields,
     double* const vr = v + (wave + kNW*rr)*pitch;
     const int fl = c*FT + wave + kNW*rr;             // its field
     const int o = (SUMS || fl >= nfields) ? 0 : opL[fl];
+#ifdef CEDR_DIAG_UP_NOLEVELS  // (diagnostic builds: the sweep without its LDS levels)
+    for (int lv = 0; lv < 0; ++lv) {
+#else
     for (int lv = 0; lv < tile.nlvl; ++lv) {
+#endif
       wave_lds_order();
       const int a = lvlL[lv];
       const int nitems = (lvlL[lv+1] - a) << LR;
@@ -609,9 +613,17 @@ void tree_up_micro_kernel (const cedr_hip_stage st, const int nfields,
     else { CEDR_WAIT_VM0_2(nab, ncc); }
 #endif
     STAMP(5);  // wait for the prefetched chunk
+#ifdef CEDR_DIAG_UP_BLOCKSTORE  // (diagnostic builds, wrong results: outputs tile-major, one contiguous block per tile)
+    if (fl < nfields)
+      for (int k = lane >> LR; k < tile.nout; k += kWave/NR)
+        data[static_cast<size_t>(160)*stride + static_cast<size_t>(tix)*nfields*16 % (stride - 4096) + fl*16 + k] = vr[outL[k]];
+#elif ! defined(CEDR_DIAG_UP_NOSTORE)  // (diagnostic builds: the sweep without its output stores)
     if (fl < nfields)
       for (int k = lane >> LR; k < tile.nout; k += kWave/NR)
         data[static_cast<size_t>(fl)*stride + tile.out + k] = vr[outL[k]];
+#else
+    if (fl < nfields && vr[outL[0]] == 1.2345e-300) data[0] = 0;
+#endif
     wave_lds_order();  // the next chunk's combines overwrite these rows
     STAMP(4);  // outputs
 #ifndef CEDR_UP_NOPREFETCH
@@ -1882,13 +1894,9 @@ inline int pitch_for (int n) { return (n + 30)/32*32 + 1; }
 // workgroup per CU slot is enough); the root->leaves kernels are limited by the
 // last, partly idle round of workgroups and prefer ~4 rounds (measured at 187 500
 // cells x 40 tracers, the 8-GPU shard: 0.117 -> 0.103 ms).
-constexpr int kSplitUp = 1024, kSplitDownDefault = 3072;  // kSplitDown: micro tiles only
-// (experiments: CEDR_HIP_SPLIT_DOWN overrides the target)
-inline int split_down_target () {
-  static const int v = [] { const char* e = std::getenv("CEDR_HIP_SPLIT_DOWN"); return e ? std::atoi(e) : kSplitDownDefault; }();
-  return v;
-}
-#define kSplitDown split_down_target()
+constexpr int kSplitUp = 1024, kSplitDown = 3072;  // kSplitDown: micro tiles only
+// (Round 2: splitting the first stage's tiles too -- 9000 or 17000 workgroups wanted -- does not shorten
+// the last, partly idle round: 0.488 -> 0.492 / 0.514 ms.)
 inline int chunk_split (int ntiles, int nchunks, int target) {
   int y = (target + ntiles - 1)/ntiles;
   if (y > nchunks) y = nchunks;

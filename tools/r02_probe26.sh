@@ -1,0 +1,11 @@
+#!/bin/bash
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+export TMPDIR=/tmp
+cd "$R"
+O=gpurun_out/r02p26
+mkdir -p $O
+V=$R/compose_amd/variants
+for v in base up_nostore up_nolevels up_neither base up_nostore up_nolevels up_neither; do
+  if [ $v = base ]; then unset CEDR_HIP_LIB; else export CEDR_HIP_LIB=$V/$v.so; fi
+  timeout -k 10 300 python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline > $O/$v.json 2> $O/b.err && { echo "== $v"; python3 tests/showbench.py $O/$v.json | grep "tree_up_kernel *launch 8192"; }
+done
