@@ -36,8 +36,8 @@ CST = 7
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--ncells", type=int, default=1500000)
     ap.add_argument("--ntracers", type=int, default=40)
     ap.add_argument("--no-cpu-baseline", action="store_true")
