@@ -466,6 +466,20 @@ def dump_plan(h, nranks=1):
             out[key].append(dict(tiles=tiles, kids=kids, lvlptr=lvlptr, max_nodes=sz[1],
                                  micro=micro[:sz[4]], outs=outs[:sz[5]]))
     out["my_root_slots"], out["my_top_slots"], out["gather_slots"] = plan_exchange(h, nranks)
+    out["apex"] = None  # the replicated top as one plain tile, if it is small enough
+    sz = (C.c_int * 6)()
+    if L.cedr_plan_stage_sizes(h, 2, 0, sz) == 0:
+        tiles = np.zeros((sz[0], 10), np.int32)
+        kids = np.zeros((sz[2], 2), np.uint16)
+        lvlptr = np.zeros(sz[3], np.int32)
+        _chk(L.cedr_plan_stage(h, 2, 0, tiles.ctypes.data_as(_ip), kids.ctypes.data_as(C.POINTER(C.c_uint16)),
+                               lvlptr.ctypes.data_as(_ip)))
+        micro = np.zeros(max(sz[4], 1), np.uint16)
+        outs = np.zeros(max(sz[5], 1), np.uint16)
+        _chk(L.cedr_plan_stage_micro(h, 2, 0, micro.ctypes.data_as(C.POINTER(C.c_uint16)),
+                                     outs.ctypes.data_as(C.POINTER(C.c_uint16))))
+        out["apex"] = dict(tiles=tiles, kids=kids, lvlptr=lvlptr, max_nodes=sz[1], micro=micro[:sz[4]],
+                           outs=outs[:sz[5]])
     return out
 
 

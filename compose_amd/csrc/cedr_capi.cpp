@@ -278,6 +278,7 @@ int cedr_plan_summary (void* h, int64_t* s) {
 }
 static const plan::Stage* get_stage (void* h, int top, int idx) {
   const plan::Plan& p = PL(h);
+  if (top == 2) return (idx == 0 && ! p.apex.tiles.empty()) ? &p.apex : nullptr;  // the apex tile
   const auto& v = top ? p.top : p.local;
   if (idx < 0 || idx >= static_cast<int>(v.size())) return nullptr;
   return &v[idx];

@@ -294,7 +294,9 @@ void cedr_plan_free(void* plan);
 void* cedr_qlt_plan(void* qlt);
 int cedr_plan_summary(void* plan, int64_t* summary8);
 /* sizes[6] = {ntiles, max_nodes, #internal nodes, #lvlptr entries, #micro entries,
- *             #outs entries}; tiles are 10 ints each (cedr_hip_tile) */
+ *             #outs entries}; tiles are 10 ints each (cedr_hip_tile).
+ * top: 0 = local stages, 1 = replicated top stages, 2 = the apex tile (idx 0; an error if the
+ * plan has none). */
 int cedr_plan_stage_sizes(void* plan, int top, int idx, int* sizes6);
 int cedr_plan_stage_micro(void* plan, int top, int idx, uint16_t* micro, uint16_t* outs);
 int cedr_plan_stage(void* plan, int top, int idx, int* tiles_x10, uint16_t* kids, int* lvlptr);

@@ -11,7 +11,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 
-def worker(rank, world, initfile, nc, pseudorandom):
+def worker(rank, world, initfile, nc, pseudorandom, use_apex):
     os.environ["CEDR_HIP_TILE_LEAVES"] = "8"
     dist.init_process_group("gloo", init_method="file://" + initfile, rank=rank, world_size=world)
     import compose_amd as ca
@@ -36,7 +36,8 @@ def worker(rank, world, initfile, nc, pseudorandom):
     bufs = [torch.zeros_like(send) for _ in range(world)]
     dist.all_gather(bufs, send)
     st.recv_records([b.numpy() for b in bufs])
-    st.top_and_down()
+    assert not use_apex or st.plan["apex"] is not None
+    st.top_and_down(use_apex)  # the top as the product's default (one apex tile) or staged
     ok = np.array_equal(st.get(len(g)), want[:, g])
     t = torch.tensor([1 if ok else 0])
     dist.all_reduce(t, op=dist.ReduceOp.MIN)
@@ -47,7 +48,7 @@ def worker(rank, world, initfile, nc, pseudorandom):
 
 
 if __name__ == "__main__":
-    for nc, pr in ((24, False), (25, True)):
+    for nc, pr, apex in ((24, False, True), (25, True, True), (25, True, False)):
         with tempfile.TemporaryDirectory() as d:
-            mp.spawn(worker, args=(2, os.path.join(d, "init"), nc, pr), nprocs=2, join=True)
+            mp.spawn(worker, args=(2, os.path.join(d, "init"), nc, pr, apex), nprocs=2, join=True)
     print("GLOO_OK")

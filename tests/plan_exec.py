@@ -240,11 +240,21 @@ class RankState:
                 if gs[r, j] >= 0:
                     self.l2r[:, gs[r, j]] = allbuf[r][j]
 
-    def top_and_down(self):
-        for st in self.plan["top"]:
-            up_stage(st, self.l2r, self.ops)
-        root_compute(self.md, int(self.plan["root_slot"]), self.l2r, self.r2l)
-        for st in reversed(self.plan["top"]):
+    def top_and_down(self, use_apex=False):
+        """use_apex: sweep the replicated top as the ONE plain tile the apex kernels use
+        (plan["apex"]) instead of the staged top; the results must be the same bits."""
+        if use_apex and self.plan.get("apex") is not None:
+            ap = self.plan["apex"]
+            up_stage(ap, self.l2r, self.ops)
+            root_compute(self.md, int(ap["tiles"][0][2]), self.l2r, self.r2l)  # the tile's output slot
+            down_stage(ap, self.md, self.l2r, self.r2l, self.prefer)
+            tops = []
+        else:
+            tops = self.plan["top"]
+            for st in tops:
+                up_stage(st, self.l2r, self.ops)
+            root_compute(self.md, int(self.plan["root_slot"]), self.l2r, self.r2l)
+        for st in reversed(tops):
             down_stage(st, self.md, self.l2r, self.r2l, self.prefer)
         if len(self.plan["top"]):
             for ts, ls in zip(self.plan["my_top_slots"], self.plan["my_root_slots"]):

@@ -34,7 +34,7 @@ def make_rank(ca, nc, P, r, tree_args, types, tile=None, monkeypatch=None):
     return q, plan_exec.RankState(q.plan(), q.metadata())
 
 
-def run_plan(ca, nc, P, tree_args, types, v, prefer=False):
+def run_plan(ca, nc, P, tree_args, types, v, prefer=False, use_apex=False):
     ranks = [make_rank(ca, nc, P, r, tree_args, types) for r in range(P)]
     for q, st in ranks:
         st.prefer = prefer
@@ -46,7 +46,9 @@ def run_plan(ca, nc, P, tree_args, types, v, prefer=False):
     for q, st in ranks:
         if P > 1:
             st.recv_records(allbuf)
-        st.top_and_down()
+        if use_apex:
+            assert st.plan["apex"] is not None
+        st.top_and_down(use_apex)
         g = q.get_owned_glblcells()
         out[:, g] = st.get(len(g))
     return out
@@ -68,6 +70,44 @@ def test_plan_execution_matches_oracle(ca, oracle, nc, P, pseudorandom, imbalanc
     want = common.run_oracle_qlt(oracle, (False, imbalanced), nc, 1, types, v)
     got = run_plan(ca, nc, P, (pseudorandom, imbalanced), types, v)
     assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("nc,P,pseudorandom,imbalanced", [
+    (2, 2, False, False), (24, 2, False, False), (60, 3, False, True), (64, 8, False, False),
+    (56, 8, True, False), (40, 4, True, True), (300, 7, False, True), (640, 64, False, False)])
+def test_apex_tile_matches_oracle(ca, oracle, nc, P, pseudorandom, imbalanced, monkeypatch):
+    """The multi-rank top as the one plain tile the apex kernels sweep (plan["apex"], <= 64
+    boundary roots): gathered records in, root problem at the tile's output, masses back at the
+    ranks' top slots -- the same bits as the staged top and as the oracle's single-rank tree."""
+    monkeypatch.setenv("CEDR_HIP_TILE_LEAVES", "8")
+    trs = R.tracers_vector()[:12]
+    types = [t.problem_type for t in trs]
+    v = R.make_values(trs, nc, seed=3*nc + P)
+    want = common.run_oracle_qlt(oracle, (False, imbalanced), nc, 1, types, v)
+    got = run_plan(ca, nc, P, (pseudorandom, imbalanced), types, v, use_apex=True)
+    assert np.array_equal(got, want)
+
+
+def test_apex_tile_shape(ca):
+    """One tile, plain (no micro table), one output; its inputs are exactly the gathered slots;
+    more than 64 boundary roots: no apex tile, the staged top is used."""
+    nc, P = 512, 8
+    tree = ca.Tree.make_1d(nc, P, True, False)  # pseudorandom ownership: many boundary roots
+    for r in range(P):
+        pl = tree.plan(nc, r, P, 0)
+        gs = pl["gather_slots"]
+        nb = int((gs >= 0).sum())
+        ap = pl["apex"]
+        if nb > 64:
+            assert ap is None
+            continue
+        assert len(ap["tiles"]) == 1 and len(ap["micro"]) == 0
+        in0, nleaf, out, nint, koff, loff, nlvl, moff, nout, ooff = [int(x) for x in ap["tiles"][0]]
+        assert nleaf == nb and nint == nb - 1 and nout == 1 and out < pl["nslots"]
+        assert set(range(in0, in0 + nleaf)) == set(int(s) for s in gs.ravel() if s >= 0)
+    pl = ca.Tree.make_1d(1024, 128).plan(1024, 5, 128, 0)
+    assert pl["apex"] is None and len(pl["top"]) >= 1
+    assert ca.Tree.make_1d(64, 1).plan(64, 0, 1, 0)["apex"] is None  # single rank: no top at all
 
 
 @pytest.mark.parametrize("tile", [2, 3, 5, 64, 256])
