@@ -49,6 +49,8 @@ _vp = C.c_void_p
 USER_ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, _vp, _vp, _vp, C.c_int, C.c_int)
 ALLGATHER_FN = C.CFUNCTYPE(C.c_int, _vp, _vp, _vp, C.c_size_t, _vp)
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, _vp, _vp, _vp, C.c_size_t, _vp)
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, _vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
+                          C.POINTER(C.c_int), _vp)
 
 
 class _QltDeviceOp(C.Structure):
@@ -67,10 +69,16 @@ _SIGS = {
     "cedr_rccl_get_unique_id": (C.c_int, [_vp]),
     "cedr_parallel_create_rccl": (_vp, [_vp, C.c_int, C.c_int]),
     "cedr_parallel_create_callbacks": (_vp, [C.c_int, C.c_int, ALLGATHER_FN, ALLREDUCE_FN, _vp]),
+    "cedr_parallel_create_callbacks_p2p": (_vp, [C.c_int, C.c_int, ALLGATHER_FN, ALLREDUCE_FN, EXCHANGE_FN, _vp]),
+    "cedr_parallel_exchange": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
+                                         C.POINTER(C.c_int), _vp]),
     "cedr_parallel_rank": (C.c_int, [_vp]),
     "cedr_parallel_size": (C.c_int, [_vp]),
     "cedr_parallel_free": (None, [_vp]),
     "cedr_tree_create": (_vp, [C.c_int, C.c_int, _ip, _ip, _ip, _lp]),
+    "cedr_tree_create_levels": (_vp, [C.c_int, C.c_int, _ip, _ip, _ip, _lp, _ip]),
+    "cedr_tree_prune": (_vp, [_vp, C.c_int]),
+    "cedr_tree_nnodes": (C.c_int, [_vp]),
     "cedr_tree_make_1d": (_vp, [C.c_int] * 4),
     "cedr_tree_free": (None, [_vp]),
     "cedr_tree_analyze": (_vp, [_vp, C.c_int, C.c_int]),
@@ -114,6 +122,9 @@ _SIGS = {
     "cedr_plan_stage": (C.c_int, [_vp, C.c_int, C.c_int, _ip, C.POINTER(C.c_uint16), _ip]),
     "cedr_plan_stage_micro": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(C.c_uint16), C.POINTER(C.c_uint16)]),
     "cedr_plan_exchange": (C.c_int, [_vp, _ip, _ip, _ip]),
+    "cedr_plan_levels": (C.c_int, [_vp, _ip]),
+    "cedr_plan_level_sizes": (C.c_int, [_vp, C.c_int, _ip]),
+    "cedr_plan_level": (C.c_int, [_vp, C.c_int, _ip, _ip, _ip, _ip, _ip]),
     "cedr_caas_create": (_vp, [_vp, C.c_int, USER_ALLREDUCE_FN, C.c_int, _vp]),
     "cedr_caas_free": (None, [_vp]),
     "cedr_caas_declare_tracer": (C.c_int, [_vp, C.c_int, C.c_int]),
@@ -146,6 +157,8 @@ _SIGS = {
     "cedr_memcpy_d2h_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "cedr_device_synchronize": (C.c_int, []),
     # kernel level (layer K) entry points used directly by tests / bench
+    "cedr_hip_level_up": (C.c_int, [_vp, C.c_int32, C.c_int32, _vp, C.c_int64, _vp, C.c_int, _vp]),
+    "cedr_hip_qlt_level_down": (C.c_int, [_vp, _vp, C.c_int32, _vp, _vp, _vp]),
     "cedr_hip_caas_nchunks": (C.c_int32, [C.c_int32]),
     "cedr_hip_caas_reduce_local": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int, _vp, _vp, _vp, _vp]),
     "cedr_hip_caas_sum_partials": (C.c_int, [C.c_int32, C.c_int32, _vp, _vp, _vp]),
@@ -341,16 +354,49 @@ class Parallel:
         return Parallel(lib().cedr_parallel_create_callbacks(rank, size, ag, ar, None), keep=(ag, ar))
 
     @staticmethod
-    def host_staged(rank, size, allgather_host, allreduce_host):
-        """Rehearsal transport: the two collectives run on HOST numpy arrays supplied by the
-        caller (e.g. torch.distributed/gloo); device buffers are staged through hipMemcpy.
-        allgather_host(send[count]) -> recv[size*count]; allreduce_host(send[count]) -> recv[count]."""
+    def callbacks_p2p(rank, size, allgather, allreduce_sum, exchange):
+        """The same plus exchange(ops, stream) -> int with ops = [(peer, device_ptr, count, is_send), ...]:
+        one round of point-to-point messages (plans in level mode: partial trees, scattered ownership)."""
+        ag = ALLGATHER_FN(lambda user, s, r, n, st: int(allgather(s, r, n, st) or 0))
+        ar = ALLREDUCE_FN(lambda user, s, r, n, st: int(allreduce_sum(s, r, n, st) or 0))
+
+        def x(user, nops, peers, bufs, counts, sends, st):
+            ops = [(peers[i], bufs[i], counts[i], bool(sends[i])) for i in range(nops)]
+            return int(exchange(ops, st) or 0)
+        xf = EXCHANGE_FN(x)
+        return Parallel(lib().cedr_parallel_create_callbacks_p2p(rank, size, ag, ar, xf, None), keep=(ag, ar, xf))
+
+    @staticmethod
+    def host_staged_p2p(rank, size, allgather_host, allreduce_host, exchange_host):
+        """host_staged plus exchange_host(sends, recvs) with sends = [(peer, array)], recvs = [(peer, count)]
+        -> list of received arrays in the order of recvs."""
+        L = lib()
+        base = Parallel._staged_ops(allgather_host, allreduce_host)
+
+        def xch(ops, st):
+            sends, recvs, rptr = [], [], []
+            for peer, ptr, n, is_send in ops:
+                if is_send:
+                    a = np.empty(n)
+                    _chk(L.cedr_memcpy_d2h_async(a.ctypes.data, ptr, a.nbytes, st), "d2h")
+                    sends.append((peer, a))
+                else:
+                    recvs.append((peer, n))
+                    rptr.append(ptr)
+            _chk(L.cedr_stream_synchronize(st), "sync")
+            got = [np.ascontiguousarray(g, np.float64) for g in exchange_host(sends, recvs)]
+            for ptr, g, (_, n) in zip(rptr, got, recvs):
+                assert g.size == n
+                _chk(L.cedr_memcpy_h2d_async(ptr, g.ctypes.data, g.nbytes, st), "h2d")
+            _chk(L.cedr_stream_synchronize(st), "sync")
+            return 0
+        return Parallel.callbacks_p2p(rank, size, base[0], base[1], xch)
+
+    @staticmethod
+    def _staged_ops(allgather_host, allreduce_host):
         L = lib()
 
         def staged(host_op):
-            # Everything on the stream the library hands over ('st' may be a non-blocking stream that
-            # the null stream does not synchronise with): the send buffer was filled by kernels on st,
-            # and the kernels that read recv follow on st.
             def f(s, r, n, st):
                 a = np.empty(n)
                 _chk(L.cedr_memcpy_d2h_async(a.ctypes.data, s, a.nbytes, st), "d2h")
@@ -360,7 +406,25 @@ class Parallel:
                 _chk(L.cedr_stream_synchronize(st), "sync")  # 'out' must outlive the copy
                 return 0
             return f
-        return Parallel.callbacks(rank, size, staged(allgather_host), staged(allreduce_host))
+        return staged(allgather_host), staged(allreduce_host)
+
+    @staticmethod
+    def host_staged(rank, size, allgather_host, allreduce_host):
+        """Rehearsal transport: the two collectives run on HOST numpy arrays supplied by the
+        caller (e.g. torch.distributed/gloo); device buffers are staged through hipMemcpy on the
+        stream the library hands over (it may be a non-blocking stream that the null stream does
+        not synchronise with: the send buffer was filled by kernels on it, the readers follow on it).
+        allgather_host(send[count]) -> recv[size*count]; allreduce_host(send[count]) -> recv[count]."""
+        return Parallel.callbacks(rank, size, *Parallel._staged_ops(allgather_host, allreduce_host))
+
+    def exchange(self, ops, stream=None):
+        """One round of point-to-point messages, ops = [(peer, device_ptr, count, is_send), ...]."""
+        n = len(ops)
+        peers = (C.c_int * n)(*[o[0] for o in ops])
+        bufs = (C.c_void_p * n)(*[o[1] for o in ops])
+        counts = (C.c_size_t * n)(*[o[2] for o in ops])
+        sends = (C.c_int * n)(*[int(o[3]) for o in ops])
+        return lib().cedr_parallel_exchange(self.h, n, peers, bufs, counts, sends, stream)
 
     def rank(self):
         return lib().cedr_parallel_rank(self.h)
@@ -401,6 +465,24 @@ class Tree:
         return Tree(lib().cedr_tree_create(len(kid0), int(root), kid0.ctypes.data_as(_ip),
                                            kid1.ctypes.data_as(_ip), rank.ctypes.data_as(_ip),
                                            cellidx.ctypes.data_as(_lp)))
+
+    @staticmethod
+    def from_arrays_levels(root, kid0, kid1, rank, cellidx, level):
+        """A PARTIAL tree (tree::Node::level, reference cedr/cedr_tree_caller.hpp:20-22): nodes above
+        the cells may lack kids; level[i] >= 0 wherever something was left out, every rank given."""
+        a = [np.ascontiguousarray(v, np.int32) for v in (kid0, kid1, rank)]
+        cellidx = np.ascontiguousarray(cellidx, np.int64)
+        level = np.ascontiguousarray(level, np.int32)
+        return Tree(lib().cedr_tree_create_levels(len(a[0]), int(root), a[0].ctypes.data_as(_ip),
+                                                  a[1].ctypes.data_as(_ip), a[2].ctypes.data_as(_ip),
+                                                  cellidx.ctypes.data_as(_lp), level.ctypes.data_as(_ip)))
+
+    def prune(self, rank):
+        """The partial tree rank `rank` needs of this (full) tree: its nodes, their kids, its ancestors."""
+        return Tree(lib().cedr_tree_prune(self.h, int(rank)))
+
+    def nnodes(self):
+        return lib().cedr_tree_nnodes(self.h)
 
     def analyze(self, ncells, rank):
         """tree::analyze -> dict of integer arrays (NodeSets, reference cedr/cedr_tree.hpp:16-97)."""
@@ -466,6 +548,17 @@ def dump_plan(h, nranks=1):
             out[key].append(dict(tiles=tiles, kids=kids, lvlptr=lvlptr, max_nodes=sz[1],
                                  micro=micro[:sz[4]], outs=outs[:sz[5]]))
     out["my_root_slots"], out["my_top_slots"], out["gather_slots"] = plan_exchange(h, nranks)
+    info = (C.c_int * 3)()
+    L.cedr_plan_levels(h, info)
+    out["level_mode"], out["root_owner"], out["steps"] = bool(info[0]), int(info[2]), []
+    for i in range(info[1]):  # per-level point-to-point steps (partial trees, scattered ownership)
+        sz = (C.c_int * 6)()
+        _chk(L.cedr_plan_level_sizes(h, i, sz))
+        arrs = [np.zeros(max(n, 1), np.int32) for n in (3 * sz[1], sz[2], sz[3], 3 * sz[4], 3 * sz[5])]
+        _chk(L.cedr_plan_level(h, i, *[a.ctypes.data_as(_ip) for a in arrs]))
+        out["steps"].append(dict(level=sz[0], nodes=arrs[0][:3 * sz[1]].reshape(-1, 3), out_slots=arrs[1][:sz[2]],
+                                 in_slots=arrs[2][:sz[3]], out_msgs=arrs[3][:3 * sz[4]].reshape(-1, 3),
+                                 in_msgs=arrs[4][:3 * sz[5]].reshape(-1, 3)))
     out["apex"] = None  # the replicated top as one plain tile, if it is small enough
     sz = (C.c_int * 6)()
     if L.cedr_plan_stage_sizes(h, 2, 0, sz) == 0:

@@ -1,5 +1,6 @@
 #include "cedr_bfb_tree_allreduce.hpp"
 
+#include <cstdlib>
 #include <memory>
 #include <vector>
 
@@ -40,7 +41,9 @@ void BfbTreeAllReducerHip::init (const mpi::Parallel::Ptr& p, const tree::FlatTr
                 "BfbTreeAllReducer does not support 0 leaves on a rank.");
   nlocal_ = static_cast<Int>(ns_->levels[0].nodes.size());
   nfield_ = nfield;
-  eng_.reset(new engine::TreeEngine(p, tree, *ns_, plan::Options()));
+  plan::Options popt;
+  if (const char* e = std::getenv("CEDR_HIP_EXCHANGE")) popt.exchange = std::atoi(e);
+  eng_.reset(new engine::TreeEngine(p, tree, *ns_, popt));
   m_.reset(new Impl());
 }
 
@@ -113,6 +116,7 @@ void BfbTreeAllReducerHip::allreduce (const Real* send, Real* recv, const bool t
     return;
   }
   eng_->up(nfield_, m_->op.data(), bd, true, s, in_rows);
+  eng_->bcast_root(nfield_, bd, s);  // level mode only: cedr_bfb_tree_allreduce.cpp:68-76, the way back down
   // The root's record is the result on every rank (:68-76 read it back from
   // the first leaf after the root->leaves copies; the value is the same).
   cedr_k_check(cedr_hip_gather_slots(bd, S, nfield_, m_->root_slot.data(), 1, recv, s));

@@ -62,6 +62,20 @@ void* cedr_parallel_create_callbacks (int rank, int size, cedr_allgather_fn ag,
   return new ParallelBox{mpi::make_parallel_callbacks(rank, size, ag, ar, user)};
   CEDR_CATCH(nullptr)
 }
+void* cedr_parallel_create_callbacks_p2p (int rank, int size, cedr_allgather_fn ag,
+                                          cedr_allreduce_sum_fn ar, cedr_exchange_fn xch, void* user) {
+  CEDR_TRY
+  return new ParallelBox{mpi::make_parallel_callbacks(rank, size, ag, ar, user, xch)};
+  CEDR_CATCH(nullptr)
+}
+int cedr_parallel_exchange (void* p, int nops, const int* peers, double* const* bufs, const size_t* counts,
+                            const int* sends, cedr_stream_t stream) {
+  CEDR_TRY
+  std::vector<mpi::Comm::P2P> ops(nops);
+  for (int i = 0; i < nops; ++i) ops[i] = mpi::Comm::P2P{peers[i], bufs[i], counts[i], sends[i]};
+  return static_cast<ParallelBox*>(p)->p->comm()->exchange(ops.data(), nops, static_cast<hipStream_t>(stream));
+  CEDR_CATCH(-1)
+}
 int cedr_parallel_rank (void* p) { return static_cast<ParallelBox*>(p)->p->rank(); }
 int cedr_parallel_size (void* p) { return static_cast<ParallelBox*>(p)->p->size(); }
 void cedr_parallel_free (void* p) { delete static_cast<ParallelBox*>(p); }
@@ -69,6 +83,18 @@ void cedr_parallel_free (void* p) { delete static_cast<ParallelBox*>(p); }
 // ---------------------------------------------------------------------- trees
 void* cedr_tree_create (int nnodes, int root, const int* kid0, const int* kid1, const int* rank,
                         const long* cellidx) {
+  return cedr_tree_create_levels(nnodes, root, kid0, kid1, rank, cellidx, nullptr);
+}
+
+void* cedr_tree_prune (void* tree, int my_rank) {
+  CEDR_TRY
+  return new TreeBox{tree::prune_for_rank(static_cast<TreeBox*>(tree)->t, my_rank)};
+  CEDR_CATCH(nullptr)
+}
+int cedr_tree_nnodes (void* tree) { return static_cast<TreeBox*>(tree)->t.size(); }
+
+void* cedr_tree_create_levels (int nnodes, int root, const int* kid0, const int* kid1, const int* rank,
+                               const long* cellidx, const int* level) {
   CEDR_TRY
   cedr_throw_if(nnodes < 1 || root < 0 || root >= nnodes, "bad tree size or root");
   TreeBox* tb = new TreeBox();
@@ -84,12 +110,18 @@ void* cedr_tree_create (int nnodes, int root, const int* kid0, const int* kid1, 
     if (it.fparent >= 0) (it.which == 0 ? t.kid0 : t.kid1)[it.fparent] = me;
     t.rank[me] = rank[it.src];
     t.cellidx[me] = cellidx[it.src];
-    const int k0 = kid0[it.src], k1 = kid1[it.src];
-    cedr_throw_if((k0 < 0) != (k1 < 0), "a node has exactly one kid; only binary trees are supported");
-    if (k0 >= 0) {
-      cedr_throw_if(k0 >= nnodes || k1 >= nnodes, "kid index out of range");
+    if (level) t.level[me] = level[it.src];
+    int k0 = kid0[it.src], k1 = kid1[it.src];
+    if (level && level[it.src] > 0 && k0 < 0 && k1 >= 0) { k0 = k1; k1 = -1; }  // partial: the one kid is kid 0
+    cedr_throw_if((k0 < 0) != (k1 < 0) && ! (level && level[it.src] > 0),
+                  "a node has exactly one kid; only binary trees are supported");
+    cedr_throw_if(k0 >= nnodes || k1 >= nnodes, "kid index out of range");
+    if (k0 >= 0 && k1 >= 0) {
       t.nkids[me] = 2;
       stack.push_back(Item{k1, me, 1});
+      stack.push_back(Item{k0, me, 0});
+    } else if (k0 >= 0) {
+      t.nkids[me] = 1;
       stack.push_back(Item{k0, me, 0});
     }
   }
@@ -254,6 +286,7 @@ void* cedr_plan_create (void* tree, int ncells, int my_rank, int nranks, int max
   if (const char* e = std::getenv("CEDR_HIP_MICRO_CUT")) o.micro_cut = std::atoi(e);
   if (const char* e = std::getenv("CEDR_HIP_MICRO_CUT2")) o.micro_cut2 = std::atoi(e);
   if (const char* e = std::getenv("CEDR_HIP_MICRO")) o.micro_all = std::atoi(e) >= 2;
+  if (const char* e = std::getenv("CEDR_HIP_EXCHANGE")) o.exchange = std::atoi(e);
   PlanBox* b = new PlanBox();
   b->owned = plan::build(t, my_rank, nranks, leaf_slot, o);
   b->p = &b->owned;
@@ -312,6 +345,36 @@ int cedr_plan_exchange (void* h, int* my_root_slots, int* my_top_slots, int* gat
   std::copy(p.my_root_slots.begin(), p.my_root_slots.end(), my_root_slots);
   std::copy(p.my_top_slots.begin(), p.my_top_slots.end(), my_top_slots);
   std::copy(p.gather_slots.begin(), p.gather_slots.end(), gather_slots);
+  return 0;
+}
+
+int cedr_plan_levels (void* h, int* info3) {
+  const plan::Plan& p = PL(h);
+  info3[0] = p.level_mode ? 1 : 0; info3[1] = static_cast<int>(p.steps.size()); info3[2] = p.root_owner;
+  return 0;
+}
+int cedr_plan_level_sizes (void* h, int i, int* sz) {
+  const plan::Plan& p = PL(h);
+  if (i < 0 || i >= static_cast<int>(p.steps.size())) { g_err = "no such level step"; return -1; }
+  const plan::LevelStep& st = p.steps[i];
+  sz[0] = st.level; sz[1] = static_cast<int>(st.nodes.size()/3);
+  sz[2] = static_cast<int>(st.out_slots.size()); sz[3] = static_cast<int>(st.in_slots.size());
+  sz[4] = static_cast<int>(st.out_msgs.size()); sz[5] = static_cast<int>(st.in_msgs.size());
+  return 0;
+}
+int cedr_plan_level (void* h, int i, int* nodes, int* out_slots, int* in_slots, int* out_msgs, int* in_msgs) {
+  const plan::Plan& p = PL(h);
+  if (i < 0 || i >= static_cast<int>(p.steps.size())) { g_err = "no such level step"; return -1; }
+  const plan::LevelStep& st = p.steps[i];
+  std::copy(st.nodes.begin(), st.nodes.end(), nodes);
+  std::copy(st.out_slots.begin(), st.out_slots.end(), out_slots);
+  std::copy(st.in_slots.begin(), st.in_slots.end(), in_slots);
+  for (size_t k = 0; k < st.out_msgs.size(); ++k) {
+    out_msgs[3*k] = st.out_msgs[k].peer; out_msgs[3*k+1] = st.out_msgs[k].first; out_msgs[3*k+2] = st.out_msgs[k].count;
+  }
+  for (size_t k = 0; k < st.in_msgs.size(); ++k) {
+    in_msgs[3*k] = st.in_msgs[k].peer; in_msgs[3*k+1] = st.in_msgs[k].first; in_msgs[3*k+2] = st.in_msgs[k].count;
+  }
   return 0;
 }
 

@@ -1,5 +1,6 @@
 #include "cedr_engine.hpp"
 
+#include <algorithm>
 #include <cstdlib>
 
 
@@ -74,6 +75,19 @@ void TreeEngine::upload () {
     my_top_slots_.upload(plan_.my_top_slots);
     gather_slots_.upload(plan_.gather_slots);
   }
+  if (plan_.level_mode) {
+    my_root_slots_.upload(plan_.my_root_slots);
+    std::vector<int32_t> nodes, outs, ins;
+    for (const auto& st : plan_.steps) {
+      lvl_off_.push_back(StepOff{nodes.size(), outs.size(), ins.size()});
+      nodes.insert(nodes.end(), st.nodes.begin(), st.nodes.end());
+      outs.insert(outs.end(), st.out_slots.begin(), st.out_slots.end());
+      ins.insert(ins.end(), st.in_slots.begin(), st.in_slots.end());
+    }
+    lvl_nodes_.upload(nodes);
+    lvl_outs_.upload(outs);
+    lvl_ins_.upload(ins);
+  }
   static const bool apex_on = [] { const char* v = std::getenv("CEDR_HIP_APEX"); return ! v || std::atoi(v) != 0; }();
   if (apex_on && ! plan_.apex.tiles.empty()) {
     apex_.reset(new DeviceStage());
@@ -111,6 +125,7 @@ void TreeEngine::up (int32_t nfields, const uint8_t* op_dev, double* data, bool 
   for (size_t i = 0; i < local_.size(); ++i)
     cedr_k_check(cedr_hip_tree_up_rows_sums(&local_[i]->h, nfields, op_dev, stride_, data,
                                             i == 0 ? in_rows : nullptr, plan_.nlcl, zero_init, all_sums_, stream));
+  if (plan_.level_mode) { up_levels(nfields, op_dev, data, zero_init, stream); return; }
   if (top_.empty()) return;
   exchange(nfields, data, stream);
   cedr_k_check(cedr_hip_scatter_slots(data, stride_, nfields, gather_slots_.data(),
@@ -144,6 +159,74 @@ const double* TreeEngine::up_to_exchange (int32_t nfields, const uint8_t* op_dev
                                             i == 0 ? in_rows : nullptr, plan_.nlcl, zero_init, all_sums_, stream));
   exchange(nfields, data, stream);
   return recvbuf_.data();
+}
+
+// ---- level mode
+void TreeEngine::up_levels (int32_t nfields, const uint8_t* op_dev, double* data, bool zero_init,
+                            hipStream_t stream) {
+  for (int32_t i = 0; i < n_level_steps(); ++i) {
+    if (level_nnodes(i))
+      cedr_k_check(cedr_hip_level_up(level_nodes(i), level_nnodes(i), nfields, op_dev, stride_, data,
+                                     zero_init, stream));
+    level_exchange(i, false, nfields, data, stream);
+  }
+}
+
+void TreeEngine::level_exchange_down (int32_t i, int32_t nfields, double* data, hipStream_t stream) {
+  level_exchange(i, true, nfields, data, stream);
+}
+
+// One round of messages of step i. Leaves->root: records at out_slots go to the parents' owners,
+// records of in_slots arrive from the kids' owners; root->leaves: the same lists, roles swapped.
+void TreeEngine::level_exchange (int32_t i, bool down, int32_t nfields, double* data, hipStream_t stream) {
+  const plan::LevelStep& st = plan_.steps[i];
+  const auto& send_slots = down ? st.in_slots : st.out_slots;
+  const auto& recv_slots = down ? st.out_slots : st.in_slots;
+  const auto& send_msgs = down ? st.in_msgs : st.out_msgs;
+  const auto& recv_msgs = down ? st.out_msgs : st.in_msgs;
+  if (send_msgs.empty() && recv_msgs.empty()) return;
+  if (nfields > xfields_) {
+    size_t most = 1;
+    for (const auto& s : plan_.steps) most = std::max(most, std::max(s.out_slots.size(), s.in_slots.size()));
+    sendbuf_.alloc_zero(most*nfields);
+    recvbuf_.alloc_zero(most*nfields);
+    xfields_ = nfields;
+  }
+  const int32_t* const send_dev = (down ? lvl_ins_.data() + lvl_off_[i].ins : lvl_outs_.data() + lvl_off_[i].outs);
+  const int32_t* const recv_dev = (down ? lvl_outs_.data() + lvl_off_[i].outs : lvl_ins_.data() + lvl_off_[i].ins);
+  if ( ! send_slots.empty())
+    cedr_k_check(cedr_hip_gather_slots(data, stride_, nfields, send_dev, static_cast<int32_t>(send_slots.size()),
+                                       sendbuf_.data(), stream));
+  std::vector<mpi::Comm::P2P> ops;
+  for (const auto& m : send_msgs)
+    ops.push_back(mpi::Comm::P2P{m.peer, sendbuf_.data() + static_cast<size_t>(m.first)*nfields,
+                                 static_cast<size_t>(m.count)*nfields, 1});
+  for (const auto& m : recv_msgs)
+    ops.push_back(mpi::Comm::P2P{m.peer, recvbuf_.data() + static_cast<size_t>(m.first)*nfields,
+                                 static_cast<size_t>(m.count)*nfields, 0});
+  const int err = p_->comm()->exchange(ops.data(), static_cast<int>(ops.size()), stream);
+  cedr_throw_if(err == -2, "this plan exchanges tree levels point to point (a partial tree, or ownership "
+                "that does not follow subtrees) but the communicator has no point-to-point exchange");
+  cedr_throw_if(err != 0, "point-to-point exchange of tree level " << st.level << " returned " << err);
+  if ( ! recv_slots.empty())
+    cedr_k_check(cedr_hip_scatter_slots(data, stride_, nfields, recv_dev, static_cast<int32_t>(recv_slots.size()),
+                                        recvbuf_.data(), stream));
+}
+
+// The root's record from its owner to every rank's root_slot. An all-gather and a pick: bitwise
+// (a sum with zeros would lose the sign of a zero).
+void TreeEngine::bcast_root (int32_t nfields, double* data, hipStream_t stream) {
+  if ( ! plan_.level_mode) return;
+  if (static_cast<size_t>(nfields)*plan_.nranks > bcast_.size()) {
+    bcast_.alloc_zero(static_cast<size_t>(nfields)*plan_.nranks);
+    bcast_send_.alloc_zero(nfields);
+    root_slot_dev_.upload(std::vector<int32_t>(1, plan_.root_slot));
+  }
+  cedr_k_check(cedr_hip_gather_slots(data, stride_, nfields, root_slot_dev_.data(), 1, bcast_send_.data(), stream));
+  const int err = p_->comm()->allgather(bcast_send_.data(), bcast_.data(), nfields, stream);
+  cedr_throw_if(err != 0, "allgather of the root record returned " << err);
+  cedr_k_check(cedr_hip_scatter_slots(data, stride_, nfields, root_slot_dev_.data(), 1,
+                                      bcast_.data() + static_cast<size_t>(plan_.root_owner)*nfields, stream));
 }
 
 void TreeEngine::top_to_local (int32_t nfields, double* data, hipStream_t stream) {

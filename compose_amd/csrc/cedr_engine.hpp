@@ -62,6 +62,19 @@ public:
   // Whether the first local stage can read through a row table (it must be a micro stage).
   bool first_stage_takes_rows () const;
 
+  // Level mode (plan::LevelStep): up() runs the local stages and then the steps in ascending
+  // level order (my nodes of the level, then the round of messages of that level); the root's
+  // record ends up on its owner only unless bcast_root is set (one small all-gather). The
+  // root->leaves direction is driven by the owner of the data (QLT::run): for every step from the
+  // last to the first, level_exchange_down() and then its own kernel over level_nodes().
+  bool level_mode () const { return plan_.level_mode; }
+  bool owns_root () const { return ! plan_.level_mode || plan_.root_owner == plan_.my_rank; }
+  int32_t n_level_steps () const { return static_cast<int32_t>(plan_.steps.size()); }
+  int32_t level_nnodes (int32_t i) const { return static_cast<int32_t>(plan_.steps[i].nodes.size()/3); }
+  const int32_t* level_nodes (int32_t i) const { return lvl_nodes_.data() + lvl_off_[i].nodes; }
+  void level_exchange_down(int32_t i, int32_t nfields, double* data, hipStream_t stream);
+  void bcast_root(int32_t nfields, double* data, hipStream_t stream);
+
   const std::vector<std::unique_ptr<DeviceStage> >& local_stages () const { return local_; }
   const std::vector<std::unique_ptr<DeviceStage> >& top_stages () const { return top_; }
   // Copy 'nfields' fields of my boundary roots from their top-stage input
@@ -76,7 +89,13 @@ private:
   std::unique_ptr<DeviceStage> apex_;
   dev::Buffer<int32_t> my_root_slots_, my_top_slots_, gather_slots_, apex_src_, apex_my_in_;
   void exchange(int32_t nfields, double* data, hipStream_t stream);
-  dev::Buffer<double> sendbuf_, recvbuf_;
+  struct StepOff { size_t nodes, outs, ins; };
+  std::vector<StepOff> lvl_off_;
+  dev::Buffer<int32_t> lvl_nodes_, lvl_outs_, lvl_ins_;
+  void level_exchange(int32_t i, bool down, int32_t nfields, double* data, hipStream_t stream);
+  void up_levels(int32_t nfields, const uint8_t* op_dev, double* data, bool zero_init, hipStream_t stream);
+  dev::Buffer<double> sendbuf_, recvbuf_, bcast_, bcast_send_;
+  dev::Buffer<int32_t> root_slot_dev_;
   int32_t xfields_ = 0;
   bool uploaded_ = false;
   bool all_sums_ = false;

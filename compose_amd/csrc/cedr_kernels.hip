@@ -1248,6 +1248,63 @@ __global__ void qlt_root_kernel (const cedr_hip_qlt_layout L, const int root_slo
   }
 }
 
+// ------------------------------------------------------------ level mode
+// The nodes a rank owns above its pure subtrees when the tree is partial or ownership is
+// scattered (plan::LevelStep): one launch per tree level, one thread per (node, field) or
+// (node, tracer), records in HBM -- the reference's own schedule (cedr_qlt.cpp:339-430, 525-604).
+// nodes[3*j] = slot of node j, then its kids' slots. Consecutive threads take consecutive nodes.
+__global__ void level_up_kernel (const int32_t* __restrict__ nodes, const int n, const int nfields,
+                                 const uint8_t* __restrict__ op, const int64_t stride,
+                                 double* __restrict__ data, const int zero_init) {
+  const int64_t idx = static_cast<int64_t>(blockIdx.x)*blockDim.x + threadIdx.x;
+  if (idx >= static_cast<int64_t>(n)*nfields) return;
+  const int j = static_cast<int>(idx % n), f = static_cast<int>(idx / n);
+  double* const row = data + static_cast<size_t>(f)*stride;
+  row[nodes[3*j]] = combine(op[f], zero_init, row[nodes[3*j + 1]], row[nodes[3*j + 2]]);
+}
+
+// r2l_solve_qp for one level (cedr_qlt.cpp:525-604): the node's assigned mass (and, for a tracer
+// that is consistent only, the global q bounds that travel with it) is in r2l at the node's slot;
+// the kids' masses go to r2l at theirs. The node's own sums are re-formed from the kids' records,
+// as the tile kernels do.
+__global__ void qlt_level_down_kernel (const cedr_hip_qlt_layout L, const int32_t* __restrict__ nodes,
+                                       const int n, double* __restrict__ l2r, double* __restrict__ r2l) {
+  const int64_t idx = static_cast<int64_t>(blockIdx.x)*blockDim.x + threadIdx.x;
+  if (idx >= static_cast<int64_t>(n)*L.nt) return;
+  const int j = static_cast<int>(idx % n), bi = static_cast<int>(idx / n);
+  const int me = nodes[3*j], c0 = nodes[3*j + 1], c1 = nodes[3*j + 2];
+  const size_t S = static_cast<size_t>(L.stride);
+  const int pt = L.bidx_prob[bi], lb = L.bidx_l2r[bi], rb = L.bidx_r2l[bi];
+  const bool sp = (pt & SHAPEPRESERVE) != 0;
+  const bool t_only = (pt & CONSISTENT) && ! sp;
+  const bool prefer = L.prefer_mass_con != 0;
+  const double rh0 = l2r[c0], rh1 = l2r[c1];
+  const double w0 = 1.0/rh0, w1 = 1.0/rh1;
+  const KidRho r0{rh0, w0, 1.0/w0}, r1{rh1, w1, 1.0/w1};
+  const double rh = rh0 + rh1;
+  const int fo = lb + (sp ? 1 : ((pt & CONSISTENT) ? 1 : 0));  // the 'orig' field
+  const double o0 = l2r[fo*S + c0], o1 = l2r[fo*S + c1];
+  const double X = r2l[rb*S + me];
+  double x0, x1;
+  if (t_only) {
+    const double qlo = r2l[(rb + 1)*S + me], qhi = r2l[(rb + 2)*S + me];
+    solve_node(pt, rh, qlo, o0 + o1, qhi, X, r0, qlo, o0, qhi, r1, qlo, o1, qhi, x0, x1, prefer);
+    r2l[(rb + 1)*S + c0] = qlo; r2l[(rb + 2)*S + c0] = qhi;
+    r2l[(rb + 1)*S + c1] = qlo; r2l[(rb + 2)*S + c1] = qhi;
+    l2r[lb*S + c0] = qlo; l2r[(lb + 2)*S + c0] = qhi;
+    l2r[lb*S + c1] = qlo; l2r[(lb + 2)*S + c1] = qhi;
+  } else {
+    double lo0 = 0, hi0 = 0, lo1 = 0, hi1 = 0;
+    if (sp) {
+      lo0 = l2r[lb*S + c0]; hi0 = l2r[(lb + 2)*S + c0];
+      lo1 = l2r[lb*S + c1]; hi1 = l2r[(lb + 2)*S + c1];
+    }
+    solve_node(pt, rh, lo0 + lo1, o0 + o1, hi0 + hi1, X, r0, lo0, o0, hi0, r1, lo1, o1, hi1, x0, x1, prefer);
+  }
+  r2l[rb*S + c0] = x0;
+  r2l[rb*S + c1] = x1;
+}
+
 // ------------------------------------------------------------------- apex
 // Multi-rank runs: the part of the tree above the ranks' pure subtrees is tiny (P boundary
 // roots for a contiguous P-way sharding) and replicated on every rank. After the all-gather of
@@ -1833,12 +1890,12 @@ __global__ void node_problem_batch_kernel (const int pt, const int nprob, const 
 // is launched on. Off by default; bench.py switches it on for its roofline leg.
 enum KernelId : int { K_TREE_UP = 0, K_QLT_DOWN, K_QLT_ROOT, K_GATHER, K_SCATTER, K_COPY,
                       K_SET_RHOM, K_SET_QM, K_GET_QM, K_CAAS_REDUCE, K_CAAS_SUM, K_CAAS_ACCUM,
-                      K_CAAS_FINISH, K_APEX, K_COUNT };
+                      K_CAAS_FINISH, K_APEX, K_LEVEL, K_COUNT };
 const char* const kKernelNames[K_COUNT] = {
   "tree_up_kernel", "qlt_down_kernel", "qlt_root_kernel", "gather_slots_kernel",
   "scatter_slots_kernel", "copy_slots_kernel", "qlt_set_rhom_kernel", "qlt_set_Qm_kernel",
   "qlt_get_Qm_kernel", "caas_reduce_kernel", "caas_sum_partials_kernel",
-  "caas_reduce_accum_kernel", "caas_finish_kernel", "apex_kernel" };
+  "caas_reduce_accum_kernel", "caas_finish_kernel", "apex_kernel", "level_kernel" };
 
 struct ProfRec { int id; int64_t aux; hipEvent_t a, b; };
 struct Profiler {
@@ -2081,6 +2138,26 @@ int cedr_hip_qlt_root (const cedr_hip_qlt_layout* lay, int32_t root_slot, const 
   ProfScope ps(K_QLT_ROOT, 0, stream);
   hipLaunchKernelGGL(qlt_root_kernel, dim3((lay->nt + 63)/64), dim3(64), 0, stream,
                      *lay, root_slot, l2r, r2l);
+  return launch_status();
+}
+
+int cedr_hip_level_up (const int32_t* nodes, int32_t n, int32_t nfields, const uint8_t* op, int64_t stride,
+                       double* data, int zero_init, cedr_stream_t stream) {
+  ProfScope ps(K_LEVEL, n, stream);
+  if (n <= 0 || nfields <= 0) return 0;
+  const int64_t items = static_cast<int64_t>(n)*nfields;
+  hipLaunchKernelGGL(level_up_kernel, dim3(static_cast<unsigned>((items + kBlock - 1)/kBlock)), dim3(kBlock), 0,
+                     stream, nodes, n, nfields, op, stride, data, zero_init);
+  return launch_status();
+}
+
+int cedr_hip_qlt_level_down (const cedr_hip_qlt_layout* lay, const int32_t* nodes, int32_t n, double* l2r,
+                             double* r2l, cedr_stream_t stream) {
+  ProfScope ps(K_LEVEL, n, stream);
+  if (n <= 0 || lay->nt <= 0) return 0;
+  const int64_t items = static_cast<int64_t>(n)*lay->nt;
+  hipLaunchKernelGGL(qlt_level_down_kernel, dim3(static_cast<unsigned>((items + kBlock - 1)/kBlock)), dim3(kBlock),
+                     0, stream, *lay, nodes, n, l2r, r2l);
   return launch_status();
 }
 

@@ -6,6 +6,7 @@
 
 #include <cstring>
 #include <mutex>
+#include <vector>
 
 #include "cedr_util.hpp"
 
@@ -40,14 +41,18 @@ struct RcclApi {
   int (*CommDestroy)(ncclComm_t);
   int (*AllGather)(const void*, void*, size_t, int, ncclComm_t, hipStream_t);
   int (*AllReduce)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t);
-  bool ok;
+  int (*Send)(const void*, size_t, int, int, ncclComm_t, hipStream_t);
+  int (*Recv)(void*, size_t, int, int, ncclComm_t, hipStream_t);
+  int (*GroupStart)();
+  int (*GroupEnd)();
+  bool ok, p2p;
 };
 
 const RcclApi& rccl () {
   static RcclApi api;
   static std::once_flag once;
   std::call_once(once, [] () {
-    api.ok = false;
+    api.ok = api.p2p = false;
     void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     // RTLD_LOCAL: a process that later loads ANOTHER librccl (PyTorch bundles its own) must not
@@ -60,8 +65,13 @@ const RcclApi& rccl () {
     api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
     api.AllGather = reinterpret_cast<decltype(api.AllGather)>(dlsym(h, "ncclAllGather"));
     api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(dlsym(h, "ncclAllReduce"));
+    api.Send = reinterpret_cast<decltype(api.Send)>(dlsym(h, "ncclSend"));
+    api.Recv = reinterpret_cast<decltype(api.Recv)>(dlsym(h, "ncclRecv"));
+    api.GroupStart = reinterpret_cast<decltype(api.GroupStart)>(dlsym(h, "ncclGroupStart"));
+    api.GroupEnd = reinterpret_cast<decltype(api.GroupEnd)>(dlsym(h, "ncclGroupEnd"));
     api.ok = api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.AllGather &&
       api.AllReduce;
+    api.p2p = api.Send && api.Recv && api.GroupStart && api.GroupEnd;
   });
   return api;
 }
@@ -111,6 +121,19 @@ struct RcclComm : public Comm {
     order_after(s);
     return e;
   }
+  int exchange (const P2P* ops, int nops, hipStream_t s) override {
+    if (nops == 0) return 0;
+    const RcclApi& a = rccl();
+    if ( ! a.p2p) return -2;
+    order_before(s);
+    int e = a.GroupStart();
+    for (int i = 0; i < nops && e == kNcclSuccess; ++i)
+      e = ops[i].send ? a.Send(ops[i].buf, ops[i].count, kNcclFloat64, ops[i].peer, comm_, s)
+                      : a.Recv(ops[i].buf, ops[i].count, kNcclFloat64, ops[i].peer, comm_, s);
+    const int e2 = a.GroupEnd();
+    order_after(s);
+    return e != kNcclSuccess ? e : e2;
+  }
 };
 
 // -------------------------------------------------------------------- callbacks
@@ -119,8 +142,9 @@ struct CallbackComm : public Comm {
   AllgatherFn ag_;
   AllreduceSumFn ar_;
   void* user_;
-  CallbackComm (int r, int s, AllgatherFn ag, AllreduceSumFn ar, void* u)
-    : rank_(r), size_(s), ag_(ag), ar_(ar), user_(u) {}
+  ExchangeFn xch_;
+  CallbackComm (int r, int s, AllgatherFn ag, AllreduceSumFn ar, void* u, ExchangeFn xch)
+    : rank_(r), size_(s), ag_(ag), ar_(ar), user_(u), xch_(xch) {}
   int rank () const override { return rank_; }
   int size () const override { return size_; }
   int allgather (const Real* send, Real* recv, size_t count, hipStream_t s) override {
@@ -128,6 +152,17 @@ struct CallbackComm : public Comm {
   }
   int allreduce_sum (const Real* send, Real* recv, size_t count, hipStream_t s) override {
     return ar_(user_, send, recv, count, s);
+  }
+  int exchange (const P2P* ops, int nops, hipStream_t s) override {
+    if (nops == 0) return 0;
+    if ( ! xch_) return -2;
+    std::vector<int> peers(nops), sends(nops);
+    std::vector<Real*> bufs(nops);
+    std::vector<size_t> counts(nops);
+    for (int i = 0; i < nops; ++i) {
+      peers[i] = ops[i].peer; sends[i] = ops[i].send; bufs[i] = ops[i].buf; counts[i] = ops[i].count;
+    }
+    return xch_(user_, nops, peers.data(), bufs.data(), counts.data(), sends.data(), s);
   }
 };
 
@@ -156,9 +191,9 @@ Parallel::Ptr make_parallel_rccl (const void* unique_id_128B, int rank, int size
 }
 
 Parallel::Ptr make_parallel_callbacks (int rank, int size, AllgatherFn ag, AllreduceSumFn ar,
-                                       void* user) {
+                                       void* user, ExchangeFn xch) {
   cedr_throw_if( ! ag || ! ar, "null collective callback");
-  return std::make_shared<Parallel>(std::make_shared<CallbackComm>(rank, size, ag, ar, user));
+  return std::make_shared<Parallel>(std::make_shared<CallbackComm>(rank, size, ag, ar, user, xch));
 }
 
 }  // namespace mpi

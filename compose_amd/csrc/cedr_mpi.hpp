@@ -32,6 +32,14 @@ struct Comm {
   virtual int allgather (const Real* send, Real* recv, size_t count, hipStream_t stream) = 0;
   // recv[i] = sum over ranks of send[i]. send and recv may alias.
   virtual int allreduce_sum (const Real* send, Real* recv, size_t count, hipStream_t stream) = 0;
+  // One round of point-to-point messages (the reference's isend / irecv / waitall of one tree
+  // level, cedr_qlt.cpp:327-337,432-439): every op of the round is posted together (one RCCL group;
+  // MPI: nonblocking + waitall), at most one send and one receive per peer and round, and the
+  // matching op is in the peer's round of the same number. Only the per-level exchange of partial
+  // trees / scattered ownership needs it (plan::Plan::level_mode); a transport without it keeps
+  // the default (an error if such a plan is run).
+  struct P2P { int peer; Real* buf; size_t count; int send; };
+  virtual int exchange (const P2P* /*ops*/, int nops, hipStream_t /*stream*/) { return nops == 0 ? 0 : -2; }
 };
 
 // What Parallel::comm() returns: the Comm of this build, usable as the shared_ptr it is -- and,
@@ -76,8 +84,12 @@ Parallel::Ptr make_parallel_rccl (const void* unique_id_128B, int rank, int size
 // Callback communicator: the host application supplies the two collectives.
 typedef int (*AllgatherFn) (void* user, const Real* send, Real* recv, size_t count, hipStream_t);
 typedef int (*AllreduceSumFn) (void* user, const Real* send, Real* recv, size_t count, hipStream_t);
+// Optional third callback: one round of point-to-point messages (Comm::exchange). peers / bufs /
+// counts / sends are arrays of nops entries.
+typedef int (*ExchangeFn) (void* user, int nops, const int* peers, Real* const* bufs, const size_t* counts,
+                           const int* sends, hipStream_t);
 Parallel::Ptr make_parallel_callbacks (int rank, int size, AllgatherFn ag, AllreduceSumFn ar,
-                                       void* user);
+                                       void* user, ExchangeFn xch = nullptr);
 
 }  // namespace mpi
 }  // namespace cedr

@@ -8,8 +8,8 @@
 //   Request, get_type<T>, reduce, all_reduce, isend, irecv, waitany, waitall, gather, gatherv,
 //   all_ok, Op                                 cedr_mpi.hpp:29-85, cedr_mpi_inl.hpp:10-66
 //
-// The CDRs' own collectives (one all-gather per QLT::run, one all-reduce per CAAS::run) go through
-// MpiComm below: MPI called on DEVICE pointers (GPU-aware MPI, what the reference requires too:
+// The CDRs' own collectives (one all-gather per QLT::run -- or, for partial trees, one round of
+// isend/irecv per tree level -- and one all-reduce per CAAS::run) go through MpiComm below: MPI called on DEVICE pointers (GPU-aware MPI, what the reference requires too:
 // cedr/cedr_test_mpi_device_ptr.cpp) after a stream synchronisation -- or, with
 // CEDR_MPI_HOST_STAGED defined (or MpiComm::host_staged = true), staged through host buffers.
 // For 8 GPUs of one node the built-in RCCL communicator (make_parallel_rccl) is the fast path;
@@ -31,7 +31,7 @@ namespace mpi {
 struct MpiComm : public Comm {
   MPI_Comm comm;
   bool host_staged;
-  std::vector<Real> hs, hr;
+  std::vector<Real> hs, hr, hx;
   explicit MpiComm (MPI_Comm c)
     : comm(c),
 #ifdef CEDR_MPI_HOST_STAGED
@@ -71,6 +71,38 @@ struct MpiComm : public Comm {
     if (hipStreamSynchronize(s) != hipSuccess) return -1;
     if (send == recv) return MPI_Allreduce(MPI_IN_PLACE, recv, n, MPI_DOUBLE, MPI_SUM, comm);
     return MPI_Allreduce(const_cast<Real*>(send), recv, n, MPI_DOUBLE, MPI_SUM, comm);
+  }
+  // One tree level's messages of a level-mode plan (partial trees): the reference's isend / irecv /
+  // waitall, cedr_qlt.cpp:327-337,432-439, with its tag.
+  int exchange (const P2P* ops, int nops, hipStream_t s) override {
+    if (nops == 0) return 0;
+    enum { tag = 42 };
+    std::vector<MPI_Request> reqs(nops);
+    std::vector<size_t> off(nops + 1, 0);
+    for (int i = 0; i < nops; ++i) off[i+1] = off[i] + ops[i].count;
+    if (host_staged) {
+      hx.resize(off[nops]);
+      for (int i = 0; i < nops; ++i)
+        if (ops[i].send && hipMemcpyAsync(hx.data() + off[i], ops[i].buf, ops[i].count*sizeof(Real),
+                                          hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
+    }
+    if (hipStreamSynchronize(s) != hipSuccess) return -1;
+    for (int i = 0; i < nops; ++i) {
+      Real* const b = host_staged ? hx.data() + off[i] : ops[i].buf;
+      const int n = static_cast<int>(ops[i].count);
+      const int e = ops[i].send ? MPI_Isend(b, n, MPI_DOUBLE, ops[i].peer, tag, comm, &reqs[i])
+                                : MPI_Irecv(b, n, MPI_DOUBLE, ops[i].peer, tag, comm, &reqs[i]);
+      if (e != MPI_SUCCESS) return e;
+    }
+    const int e = MPI_Waitall(nops, reqs.data(), MPI_STATUSES_IGNORE);
+    if (e != MPI_SUCCESS) return e;
+    if (host_staged) {
+      for (int i = 0; i < nops; ++i)
+        if ( ! ops[i].send && hipMemcpyAsync(ops[i].buf, hx.data() + off[i], ops[i].count*sizeof(Real),
+                                             hipMemcpyHostToDevice, s) != hipSuccess) return -1;
+      if (hipStreamSynchronize(s) != hipSuccess) return -1;
+    }
+    return 0;
   }
 };
 

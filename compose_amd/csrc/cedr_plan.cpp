@@ -233,6 +233,123 @@ struct Builder {
 
 }  // namespace
 
+// Level mode (cedr_plan.hpp, LevelStep). Works from what one rank knows: the nodes it owns, their
+// kids, and the chain of ancestors, with explicit ranks and levels wherever the tree is pruned.
+static Plan build_level_mode (const tree::FlatTree& t, const int32_t me, const int32_t nranks,
+                       const std::vector<int32_t>& leaf_slot, const Options& opt) {
+  const int32_t nn = t.size();
+  Plan p;
+  p.my_rank = me;
+  p.nranks = nranks;
+  p.level_mode = true;
+
+  // Ranks of internal nodes default to kid 0's (cedr_tree.cpp:45); levels to the height, unless
+  // the caller gives them; pure[n]: n and everything below it is mine and present.
+  std::vector<int32_t> rank(t.rank.begin(), t.rank.end()), lvl(nn, 0);
+  std::vector<char> pure(nn, 0);
+  for (const Int n : tree::post_order(t)) {
+    int32_t h = -1;
+    for (Int i = 0; i < t.nkids[n]; ++i) h = std::max(h, lvl[t.kid(n, i)]);
+    lvl[n] = t.level[n] >= 0 ? t.level[n] : h + 1;
+    if (rank[n] < 0 && t.nkids[n] > 0) rank[n] = rank[t.kid0[n]];
+    cedr_throw_if(rank[n] < 0 || rank[n] >= nranks, "a tree node has no valid rank: " << rank[n]);
+    if (rank[n] != me) continue;
+    if (t.nkids[n] == 0) {
+      cedr_throw_if(lvl[n] != 0, "an owned node without kids is a cell and must be at level 0");
+      pure[n] = 1;
+    } else {
+      cedr_throw_if(t.nkids[n] != 2, "Only binary trees are supported: an owned node has "
+                    << t.nkids[n] << " kids.");
+      for (Int i = 0; i < 2; ++i)
+        cedr_throw_if(lvl[t.kid(n, i)] >= lvl[n], "a kid's level is not below its parent's");
+      pure[n] = pure[t.kid0[n]] && pure[t.kid1[n]];
+    }
+  }
+  p.root_owner = rank[0];
+
+  Builder b(t, opt);
+  for (int32_t n = 0; n < nn; ++n)
+    if (t.nkids[n] == 0 && rank[n] == me) {
+      cedr_throw_if(leaf_slot[n] < 0, "owned leaf without a local index");
+      b.slot[n] = leaf_slot[n];
+      ++p.nlcl;
+    }
+  b.next_slot = p.nlcl;
+
+  // Roots of my maximal pure subtrees, DFS order (node indices are pre-order): tile stages.
+  std::vector<int32_t> my_roots;
+  for (int32_t n = 0; n < nn; ++n)
+    if (pure[n] && (t.parent[n] < 0 || ! pure[t.parent[n]])) my_roots.push_back(n);
+  b.tile_forest(my_roots, p.local, opt.micro ? (opt.micro_all ? 2 : 1) : 0, true);
+  for (const int32_t r : my_roots) p.my_root_slots.push_back(b.slot[r]);
+
+  // Slots of the rest of my nodes and of their kids elsewhere.
+  for (int32_t n = 0; n < nn; ++n) {
+    if (rank[n] != me || pure[n]) continue;
+    if (b.slot[n] < 0) b.slot[n] = b.next_slot++;
+    for (Int i = 0; i < 2; ++i) {
+      const int32_t c = t.kid(n, i);
+      if (b.slot[c] < 0) b.slot[c] = b.next_slot++;
+    }
+  }
+  p.root_slot = b.slot[0] >= 0 ? b.slot[0] : b.next_slot++;
+  p.nslots = b.next_slot;
+
+  // Steps. (peer, slot) lists in DFS order, then grouped by peer with a stable sort.
+  struct Ev { int32_t level, peer, slot; };
+  std::vector<Ev> outs, ins;
+  std::vector<std::pair<int32_t,int32_t> > mine;  // (level, node)
+  for (int32_t n = 0; n < nn; ++n) {
+    if (rank[n] != me) continue;
+    const int32_t par = t.parent[n];
+    if (par >= 0 && rank[par] != me) outs.push_back(Ev{lvl[n], rank[par], b.slot[n]});
+    if (pure[n]) continue;
+    mine.push_back(std::make_pair(lvl[n], n));
+    for (Int i = 0; i < 2; ++i) {
+      const int32_t c = t.kid(n, i);
+      if (rank[c] != me) ins.push_back(Ev{lvl[c], rank[c], b.slot[c]});
+    }
+  }
+  const auto by_level_peer = [] (const Ev& a, const Ev& c) {
+    return a.level != c.level ? a.level < c.level : a.peer < c.peer;
+  };
+  std::stable_sort(outs.begin(), outs.end(), by_level_peer);
+  std::stable_sort(ins.begin(), ins.end(), by_level_peer);
+  std::stable_sort(mine.begin(), mine.end(),
+                   [] (const std::pair<int32_t,int32_t>& a, const std::pair<int32_t,int32_t>& c) {
+                     return a.first < c.first; });
+  std::vector<int32_t> levels;
+  for (const Ev& e : outs) levels.push_back(e.level);
+  for (const Ev& e : ins) levels.push_back(e.level);
+  for (const auto& m : mine) levels.push_back(m.first);
+  std::sort(levels.begin(), levels.end());
+  levels.erase(std::unique(levels.begin(), levels.end()), levels.end());
+  size_t io = 0, ii = 0, im = 0;
+  const auto fill = [] (const std::vector<Ev>& ev, size_t& i, const int32_t L, std::vector<int32_t>& slots,
+                        std::vector<LevelStep::Msg>& msgs) {
+    for (; i < ev.size() && ev[i].level == L; ++i) {
+      if (msgs.empty() || msgs.back().peer != ev[i].peer)
+        msgs.push_back(LevelStep::Msg{ev[i].peer, static_cast<int32_t>(slots.size()), 0});
+      ++msgs.back().count;
+      slots.push_back(ev[i].slot);
+    }
+  };
+  for (const int32_t L : levels) {
+    LevelStep st;
+    st.level = L;
+    for (; im < mine.size() && mine[im].first == L; ++im) {
+      const int32_t n = mine[im].second;
+      st.nodes.push_back(b.slot[n]);
+      st.nodes.push_back(b.slot[t.kid0[n]]);
+      st.nodes.push_back(b.slot[t.kid1[n]]);
+    }
+    fill(outs, io, L, st.out_slots, st.out_msgs);
+    fill(ins, ii, L, st.in_slots, st.in_msgs);
+    p.steps.push_back(std::move(st));
+  }
+  return p;
+}
+
 Plan build (const tree::FlatTree& t, int32_t my_rank, int32_t nranks,
             const std::vector<int32_t>& leaf_slot, const Options& opt) {
   const int32_t nn = t.size();
@@ -242,19 +359,31 @@ Plan build (const tree::FlatTree& t, int32_t my_rank, int32_t nranks,
   p.my_rank = my_rank;
   p.nranks = nranks;
 
+  // "If providing only partial trees, set level" (cedr_tree_caller.hpp:20-22): a caller that sets
+  // levels says its trees may be partial. Whether THIS rank's tree has anything missing cannot
+  // decide it -- a rank whose part happens to be complete must still pick the same protocol as the
+  // others.
+  bool partial = false;
+  for (int32_t n = 0; n < nn; ++n)
+    if (t.level[n] >= 0 || (t.nkids[n] != 2 && t.nkids[n] != 0)) partial = true;
+  cedr_throw_if(partial && opt.exchange == 1,
+                "a partial tree (Node::level) cannot use the all-gather exchange");
+  if (nranks > 1 && (partial || opt.exchange == 2)) return build_level_mode(t, my_rank, nranks, leaf_slot, opt);
+
   // own[n]: the rank owning every leaf below n, or -1 if more than one does.
   std::vector<int32_t> own(nn, -1);
+  int64_t ncells = 0;
   for (const Int n : tree::post_order(t)) {
     if (t.nkids[n] == 0) {
       cedr_throw_if(t.rank[n] < 0 || t.rank[n] >= nranks, "leaf rank out of range");
       own[n] = t.rank[n];
+      ++ncells;
     } else {
       cedr_throw_if(t.nkids[n] != 2, "Only binary trees are supported: a node has "
                     << t.nkids[n] << " kids.");
       const int32_t a = own[t.kid0[n]], b = own[t.kid1[n]];
       own[n] = (a >= 0 && a == b) ? a : -1;
     }
-    cedr_throw_if(t.level[n] >= 0, "Partial trees (Node::level) are not supported by this build.");
   }
 
   // Boundary roots = roots of maximal single-rank subtrees, in DFS order.
@@ -268,6 +397,17 @@ Plan build (const tree::FlatTree& t, int32_t my_rank, int32_t nranks,
       stack.push_back(t.kid1[n]);
       stack.push_back(t.kid0[n]);
     }
+  }
+
+  if (opt.exchange == 0 && nranks > 1) {
+    // The all-gather hands every rank nranks*nb_max records and the sweeps over them; a rank's own
+    // share of the tree is ~2*ncells/nranks nodes. Scattered ownership (nb_max ~ ncells/nranks)
+    // makes the first nranks/2 times the second: per-level messages instead, unless the whole
+    // thing is so small that ~2*depth rounds of messages cost more than the replicated sweeps.
+    std::vector<int64_t> per_rank(nranks, 0);
+    for (const int32_t r : broots) ++per_rank[own[r]];
+    const int64_t nb_max = *std::max_element(per_rank.begin(), per_rank.end());
+    if (nranks*nb_max > 16384 + 2*ncells/nranks) return build_level_mode(t, my_rank, nranks, leaf_slot, opt);
   }
 
   Builder b(t, opt);

@@ -67,6 +67,25 @@ struct Stage {
   std::vector<uint16_t> outs;
 };
 
+// LEVEL MODE. When the caller hands every rank only its part of the tree (tree::Node::level,
+// cedr_tree_caller.hpp:20-22) the part above a rank's pure subtrees cannot be replicated, and when
+// ownership does not follow subtrees (oned::Mesh pseudorandom) replicating it costs O(N) per rank.
+// Then a rank keeps the tile stages for the pure subtrees it owns and walks the REST of what it
+// owns -- nodes with at least one descendant it does not own -- one tree level per step, as the
+// reference does (cedr_qlt.cpp:618-640), with one round of point-to-point messages per step:
+// leaves->root, the records of my level-L nodes whose parent another rank owns go out and those
+// of the level-L kids of my nodes come in; root->leaves the same messages run backwards. Between
+// two ranks and one step there is at most one message per direction; its records are in DFS
+// order, which both sides can compute from their own (partial) trees.
+struct LevelStep {
+  int32_t level = 0;               // tree level (leaf = 0) of this step's nodes and messages
+  std::vector<int32_t> nodes;      // 3 per node of mine at this level: its slot, kid 0's, kid 1's
+  struct Msg { int32_t peer, first, count; };  // 'count' records from entry 'first' of the slot list
+  std::vector<int32_t> out_slots;  // my nodes of this level with a parent elsewhere, grouped by peer
+  std::vector<int32_t> in_slots;   // other ranks' nodes of this level whose parent is mine
+  std::vector<Msg> out_msgs, in_msgs;
+};
+
 struct Plan {
   int32_t my_rank = 0, nranks = 1;
   int32_t nlcl = 0;       // cells owned by this rank; their slots are 0..nlcl-1 in
@@ -88,6 +107,13 @@ struct Plan {
   std::vector<int32_t> my_top_slots;     // the same roots' slots as inputs of 'top'
   std::vector<int32_t> gather_slots;     // [nranks*nb_max] top input slot of rank r's
                                          // j-th boundary root, or -1 for padding
+
+  // Level mode (see LevelStep): 'top', 'apex' and the gather tables are empty; my_root_slots are
+  // the roots of this rank's pure subtrees; root_slot holds the root's record on root_owner only
+  // (the BFB reducer broadcasts it).
+  bool level_mode = false;
+  std::vector<LevelStep> steps;          // ascending level
+  int32_t root_owner = 0;
 };
 
 struct Options {
@@ -98,6 +124,12 @@ struct Options {
   int32_t micro_cut2 = 2;         // the same for the second stage (micro_all only; 0 = keep all): cutting
                                   // it moves tree levels from the second to the third stage, which
                                   // otherwise has only a handful of tiles, at no cost in stages
+  // How the part of the tree above the ranks' pure subtrees is handled on more than one rank:
+  // 0 = decide (level mode for partial trees and when the gathered boundary roots would outnumber
+  // a rank's fair share of the cells several times over), 1 = one all-gather + replicated top,
+  // 2 = level mode. Every rank must use the same value; the automatic rule only looks at numbers
+  // every rank computes alike.
+  int32_t exchange = 0;
 };
 
 // 'leaf_slot[n]' gives, for every tree node n that is a leaf owned by my_rank,

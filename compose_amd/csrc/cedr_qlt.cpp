@@ -122,6 +122,8 @@ void QLTHip::init (const Parallel::Ptr& p, const Int& ncells, const tree::FlatTr
   }
   if (const char* e = std::getenv("CEDR_HIP_MICRO_CUT")) popt.micro_cut = std::atoi(e);
   if (const char* e = std::getenv("CEDR_HIP_MICRO_CUT2")) popt.micro_cut2 = std::atoi(e);
+  // 1 = all-gather + replicated top, 2 = per-level point-to-point; default: decided from the tree
+  if (const char* e = std::getenv("CEDR_HIP_EXCHANGE")) popt.exchange = std::atoi(e);
   eng_.reset(new engine::TreeEngine(p, tree, *ns_, popt));
   mdb_.reset(new std::vector<int>());
   d_.reset(new Impl());
@@ -372,7 +374,17 @@ void QLTHip::run () {
                                        d.b_qm + ti*n, d.b_min + ti*n, d.b_max + ti*n,
                                        d.b_prev ? d.b_prev + ti*n : nullptr, o.l2r_data, s));
   }
-  if (eng_->has_apex()) {
+  if (eng_->level_mode()) {
+    // Partial tree / scattered ownership: what this rank owns above its pure subtrees goes level by
+    // level with one round of messages per level (reference QLT::run, cedr_qlt.cpp:618-640).
+    eng_->up(d.lay.l2rndps, d.lay.l2r_op, d.l2r, false, s, rows_mode ? d.in_rows.data() : nullptr);
+    if (eng_->owns_root())
+      cedr_k_check(cedr_hip_qlt_root(&d.lay, eng_->get_plan().root_slot, d.l2r, d.r2l, s));
+    for (int32_t i = eng_->n_level_steps(); i > 0; --i) {
+      eng_->level_exchange_down(i-1, d.lay.r2lndps, d.r2l, s);
+      cedr_k_check(cedr_hip_qlt_level_down(&d.lay, eng_->level_nodes(i-1), eng_->level_nnodes(i-1), d.l2r, d.r2l, s));
+    }
+  } else if (eng_->has_apex()) {
     // Ranks own whole subtrees and the tree above them is small: after the local sweeps and the
     // ONE all-gather, one single-workgroup launch does the replicated top (both directions and
     // root_compute) and hands this rank's boundary roots their masses.

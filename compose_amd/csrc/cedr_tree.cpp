@@ -63,6 +63,45 @@ std::vector<Int> post_order (const FlatTree& t) {
   return order;
 }
 
+FlatTree prune_for_rank (const FlatTree& full, const Int me) {
+  const Int nn = full.size();
+  cedr_throw_if(nn == 0, "empty tree");
+  std::vector<Int> rank(full.rank), lvl(nn, 0);
+  std::vector<char> keep(nn, 0);
+  const std::vector<Int> order = post_order(full);
+  for (const Int n : order) {
+    Int h = -1;
+    for (Int i = 0; i < full.nkids[n]; ++i) h = std::max(h, lvl[full.kid(n, i)]);
+    lvl[n] = full.level[n] >= 0 ? full.level[n] : h + 1;
+    if (rank[n] < 0 && full.nkids[n] > 0) rank[n] = rank[full.kid0[n]];
+    // mine, or above something of mine
+    if (rank[n] == me) keep[n] = 1;
+    for (Int i = 0; i < full.nkids[n]; ++i) if (keep[full.kid(n, i)]) keep[n] = 1;
+  }
+  for (Int n = 0; n < nn; ++n)  // kids of my nodes (kept so far means: mine or an ancestor)
+    if (rank[n] == me)
+      for (Int i = 0; i < full.nkids[n]; ++i) if ( ! keep[full.kid(n, i)]) keep[full.kid(n, i)] = 2;
+  keep[0] = keep[0] ? keep[0] : 1;
+  FlatTree out;
+  std::vector<std::pair<Int,Int> > stack(1, std::make_pair(0, -1));  // (full node, parent in out)
+  while ( ! stack.empty()) {
+    const std::pair<Int,Int> it = stack.back();
+    stack.pop_back();
+    const Int n = it.first, o = out.add(it.second);
+    if (it.second >= 0) {
+      if (out.kid0[it.second] < 0) out.kid0[it.second] = o; else out.kid1[it.second] = o;
+      ++out.nkids[it.second];
+    }
+    out.rank[o] = rank[n];
+    out.level[o] = lvl[n];
+    out.cellidx[o] = full.nkids[n] == 0 ? full.cellidx[n] : -1;
+    if (keep[n] == 2 && rank[n] != me) continue;  // somebody else's kid of mine: nothing below it matters
+    for (Int i = full.nkids[n] - 1; i >= 0; --i)
+      if (keep[full.kid(n, i)]) stack.push_back(std::make_pair(full.kid(n, i), o));
+  }
+  return out;
+}
+
 void NodeSets::print (std::ostream& os) const {  // reference cedr_tree.cpp:8-34
   std::stringstream ss;
   if (levels.empty()) return;
@@ -151,7 +190,7 @@ NodeSets::ConstPtr analyze (const Int my_rank, const Int& ncells, FlatTree t) {
       Int h = 0;
       for (Int i = 0; i < t.nkids[n]; ++i) h = std::max(h, height[t.kid(n, i)]);
       height[n] = h + 1;
-      if (t.rank[n] < 0) t.rank[n] = t.rank[t.kid0[n]];
+      if (t.rank[n] < 0 && t.nkids[n] > 0) t.rank[n] = t.rank[t.kid0[n]];
       t.cellidx[n] = id++;
     } else {
       cedr_throw_if(t.rank[n] == my_rank && (t.cellidx[n] < 0 || t.cellidx[n] >= id),

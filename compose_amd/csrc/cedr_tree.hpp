@@ -28,6 +28,11 @@ FlatTree flatten(const Node::Ptr& tree);
 // Node indices in post-order: kid 0's subtree, kid 1's subtree, then the node.
 std::vector<Int> post_order(const FlatTree& t);
 
+// The part of a full tree rank 'my_rank' has to know, as a PARTIAL tree (cedr_tree_caller.hpp:20-22):
+// the nodes it owns, their kids, and every ancestor of those, with ranks and levels filled in and
+// everything else pruned away. O(cells/ranks + depth) nodes.
+FlatTree prune_for_rank(const FlatTree& full, Int my_rank);
+
 // reference cedr/cedr_tree.hpp:16-97
 struct NodeSets {
   typedef std::shared_ptr<const NodeSets> ConstPtr;

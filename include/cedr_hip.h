@@ -108,6 +108,15 @@ int cedr_hip_qlt_down_rows(const cedr_hip_qlt_layout* lay, const cedr_hip_stage*
                            double* l2r, double* r2l, const double* const* in_rows,
                            double* const* out_rows, int32_t nrow, cedr_stream_t stream);
 
+/* Level mode (partial caller trees, ownership that does not follow subtrees): the nodes a rank
+ * owns above its pure subtrees, one launch per tree level as in the reference (cedr_qlt.cpp:339-430
+ * l2r_combine_kid_data, :525-604 r2l_solve_qp). nodes[3*j] = slot of node j, nodes[3*j+1..2] = its
+ * kids' slots; data is field-major with `stride` doubles per field. */
+int cedr_hip_level_up(const int32_t* nodes, int32_t n, int32_t nfields, const uint8_t* op, int64_t stride,
+                      double* data, int zero_init, cedr_stream_t stream);
+int cedr_hip_qlt_level_down(const cedr_hip_qlt_layout* lay, const int32_t* nodes, int32_t n, double* l2r,
+                            double* r2l, cedr_stream_t stream);
+
 /* QLT::root_compute (cedr_qlt.cpp:441-476). */
 int cedr_hip_qlt_root(const cedr_hip_qlt_layout* lay, int32_t root_slot,
                       const double* l2r, double* r2l, cedr_stream_t stream);
@@ -215,6 +224,18 @@ typedef int (*cedr_allreduce_sum_fn)(void* user, const double* send, double* rec
                                      cedr_stream_t stream);
 void* cedr_parallel_create_callbacks(int rank, int size, cedr_allgather_fn ag,
                                      cedr_allreduce_sum_fn ar, void* user);
+/* The same plus one round of point-to-point messages (the reference's isend/irecv/waitall of one
+ * tree level, cedr_qlt.cpp:327-337,432-439): op i sends (sends[i] != 0) or receives counts[i]
+ * doubles at device pointer bufs[i] to / from rank peers[i]; all ops of a call are posted together;
+ * at most one send and one receive per peer. Needed only by plans in level mode (partial trees). */
+typedef int (*cedr_exchange_fn)(void* user, int nops, const int* peers, double* const* bufs,
+                                const size_t* counts, const int* sends, cedr_stream_t stream);
+void* cedr_parallel_create_callbacks_p2p(int rank, int size, cedr_allgather_fn ag,
+                                         cedr_allreduce_sum_fn ar, cedr_exchange_fn xch, void* user);
+/* One round of point-to-point messages through a Parallel's own transport (what level-mode plans
+ * use between tree levels); arguments as cedr_exchange_fn. */
+int cedr_parallel_exchange(void* p, int nops, const int* peers, double* const* bufs, const size_t* counts,
+                           const int* sends, cedr_stream_t stream);
 int cedr_parallel_rank(void* p);
 int cedr_parallel_size(void* p);
 void cedr_parallel_free(void* p);
@@ -224,6 +245,16 @@ void cedr_parallel_free(void* p);
  * at leaves (rank >= 0 at an internal node pins that node's rank). */
 void* cedr_tree_create(int nnodes, int root, const int* kid0, const int* kid1, const int* rank,
                        const long* cellidx);
+/* The same with tree::Node::level (cedr_tree_caller.hpp:20-22) for PARTIAL trees: a rank passes only
+ * the nodes it owns, their kids and the chain of ancestors. level[i] >= 0 is the node's level (leaf
+ * = 0), required wherever a subtree is left out; a node may then have one kid (kid1 = -1) or none
+ * although it is not a cell; every node needs its rank. level == NULL: cedr_tree_create. */
+void* cedr_tree_create_levels(int nnodes, int root, const int* kid0, const int* kid1, const int* rank,
+                              const long* cellidx, const int* level);
+/* What rank `my_rank` needs of a full tree, as a new partial tree with levels and ranks filled in
+ * (what E3SM builds directly for large rank counts). */
+void* cedr_tree_prune(void* tree, int my_rank);
+int cedr_tree_nnodes(void* tree);
 /* tree::make_tree_over_1d_mesh / oned::make_tree (cedr_tree.cpp:350-420). */
 void* cedr_tree_make_1d(int ncells, int nranks, int pseudorandom, int imbalanced);
 void cedr_tree_free(void* tree);
@@ -302,6 +333,15 @@ int cedr_plan_stage_micro(void* plan, int top, int idx, uint16_t* micro, uint16_
 int cedr_plan_stage(void* plan, int top, int idx, int* tiles_x10, uint16_t* kids, int* lvlptr);
 /* my_root_slots[#my roots], my_top_slots[#my roots], gather_slots[nranks*nb_max] */
 int cedr_plan_exchange(void* plan, int* my_root_slots, int* my_top_slots, int* gather_slots);
+
+/* Level mode (partial trees / scattered ownership; plan::LevelStep in csrc/cedr_plan.hpp).
+ * info[3] = {level mode?, #steps, rank owning the root}; sizes[6] of step i = {tree level, #nodes,
+ * #out slots, #in slots, #out messages, #in messages}; nodes are (slot, kid 0 slot, kid 1 slot),
+ * messages (peer, first entry of the slot list, count). */
+int cedr_plan_levels(void* plan, int* info3);
+int cedr_plan_level_sizes(void* plan, int i, int* sizes6);
+int cedr_plan_level(void* plan, int i, int* nodes_x3, int* out_slots, int* in_slots, int* out_msgs_x3,
+                    int* in_msgs_x3);
 
 /* -- cedr::caas::CAAS (reference cedr/cedr_caas.hpp:51-96) ------------------ */
 /* UserAllReducer (cedr_caas.hpp:27-49) as a callback; NULL = own all-reduce. */

@@ -1,6 +1,7 @@
 // The CDRs over a real MPI communicator (mpiexec, N processes sharing GPU 0): the opt-in adapter
 // cedr_mpi_adapter.hpp carries QLT's all-gather, CAAS's all-reduce and the BFB reducer's all-gather
-// (host staged: the image's MPICH is not GPU aware). Every rank also runs the same global problem
+// (host staged: the image's MPICH is not GPU aware); QLT also runs from per-rank PARTIAL trees, whose
+// tree levels travel as isend/irecv rounds. Every rank also runs the same global problem
 // alone (cedr::mpi::make_parallel(), one rank) and compares its own cells: QLT and BFB bit for
 // bit, CAAS to 1e-13 per tracer (N partial sums are added in another order than one rank's).
 // The reference's counterpart: `mpirun -np 8 cedr_test -t` (cedr/CMakeLists.txt:14-16).
@@ -12,11 +13,13 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <stdexcept>
 #include <vector>
 
 #include "cedr_mpi_adapter.hpp"
 #include "cedr_bfb_tree_allreduce.hpp"
 #include "cedr_caas.hpp"
+#include "cedr_engine.hpp"
 #include "cedr_qlt.hpp"
 
 using cedr::Int;
@@ -66,8 +69,12 @@ int main (int argc, char** argv) {
       for (int i = 0; i < nc; ++i) Qm[(size_t) t*nc + i] = prev[(size_t) t*nc + (i*7919 + 13) % nc];  // permuted
       if (pts[t] & PT::nonnegative) for (int i = 0; i < nc; ++i) prev[(size_t) t*nc + i] = Qm[(size_t) t*nc + i];
     }
-    auto run_qlt = [&] (const cedr::mpi::Parallel::Ptr& p, std::vector<cedr::Long>& g) {
-      cedr::qlt::QLT<> q(p, nc, cedr::tree::make_tree_over_1d_mesh(p, nc, false));
+    // partial: the rank passes only its part of the tree (tree::Node::level) -> per-level isend/irecv
+    auto run_qlt = [&] (const cedr::mpi::Parallel::Ptr& p, std::vector<cedr::Long>& g, const bool partial = false) {
+      cedr::tree::FlatTree ft = cedr::tree::flatten(cedr::tree::make_tree_over_1d_mesh(p, nc, false));
+      if (partial) ft = cedr::tree::prune_for_rank(ft, p->rank());
+      cedr::qlt::QLT<> q(p, nc, ft);
+      if (partial && p->size() > 1 && ! q.tree_engine().level_mode()) throw std::runtime_error("expected level mode");
       for (int t = 0; t < nt; ++t) q.declare_tracer(pts[t], 0);
       q.end_tracer_declarations();
       q.finish_setup();
@@ -94,6 +101,14 @@ int main (int argc, char** argv) {
     for (int t = 0; t < nt; ++t) for (size_t i = 0; i < gm.size(); ++i)
       if (std::memcmp(&mine[t*gm.size() + i], &refg[(size_t) t*nc + gm[i]], sizeof(Real))) ++nq;
     if (nq) { std::printf("rank %d FAIL QLT over MPI differs from the single-rank run in %d values\n", rank, nq); nerr += nq; }
+    {
+      std::vector<cedr::Long> gp;
+      const std::vector<Real> part = run_qlt(pm, gp, true);
+      int np = gp.size() == gm.size() ? 0 : 1;
+      for (int t = 0; t < nt && ! np; ++t) for (size_t i = 0; i < gp.size(); ++i)
+        if (std::memcmp(&part[t*gp.size() + i], &refg[(size_t) t*nc + gp[i]], sizeof(Real))) ++np;
+      if (np) { std::printf("rank %d FAIL QLT over partial trees differs in %d values\n", rank, np); nerr += np; }
+    }
 
     {  // CAAS, contiguous split, shape-preserving tracers only (cedr_caas.cpp:52-53)
       const int ct = 3;  // the first three tracers

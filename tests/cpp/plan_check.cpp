@@ -112,7 +112,7 @@ static void check (const tree::FlatTree& t, const int ncells, const int nranks, 
       for (const int s : pl.gather_slots) nb += s >= 0;
       REQUIRE(nb > plan::Plan::kApexMaxInputs);  // the apex tile is only left out when it would be too large
     }
-    if (nranks > 1) {
+    if (nranks > 1 && ! pl.level_mode) {
       REQUIRE((int) pl.gather_slots.size() == nranks*pl.nb_max);
       REQUIRE(pl.my_root_slots.size() == pl.my_top_slots.size());
       REQUIRE((int) pl.my_root_slots.size() <= pl.nb_max);
@@ -120,6 +120,78 @@ static void check (const tree::FlatTree& t, const int ncells, const int nranks, 
       for (const int s : pl.my_root_slots) REQUIRE(s >= 0 && s < pl.nslots);
       for (const int s : pl.my_top_slots) REQUIRE(s >= 0 && s < pl.nslots);
     }
+  }
+}
+
+// Level mode (partial trees / per-level point-to-point): every rank plans from its own tree; the
+// ranks' message lists must pair up, every slot a step reads must have been produced before it.
+static void check_level (const tree::FlatTree& full, const int ncells, const int nranks, plan::Options opt,
+                         const bool partial, const char* ctx) {
+  if (nranks < 2) return;
+  if ( ! partial) opt.exchange = 2;
+  std::vector<plan::Plan> pls(nranks);
+  for (int me = 0; me < nranks; ++me) {
+    const tree::FlatTree t = partial ? tree::prune_for_rank(full, me) : full;
+    const auto ns = tree::analyze(me, ncells, t);
+    util::IdMap g2l;
+    for (const Int idx : ns->levels[0].nodes) g2l.add(ns->node_h(idx)->id, ns->node_h(idx)->offset);
+    g2l.finish();
+    std::vector<int32_t> leaf_slot(t.size(), -1);
+    for (Int n = 0; n < t.size(); ++n)
+      if (t.nkids[n] == 0 && t.rank[n] == me) leaf_slot[n] = g2l.find((Int) t.cellidx[n]);
+    plan::Plan& pl = pls[me];
+    try { pl = plan::build(t, me, nranks, leaf_slot, opt); }
+    catch (const std::logic_error& e) { std::printf("FAIL %s: rank %d: %s\n", ctx, me, e.what()); ++g_fail; return; }
+    REQUIRE(pl.level_mode && pl.top.empty() && pl.apex.tiles.empty());
+    const int64_t stride = ((int64_t) pl.nslots + 2 + 15)/16*16;
+    for (size_t i = 0; i < pl.local.size(); ++i) check_stage(pl.local[i], pl, stride, i == 0, ctx);
+    REQUIRE(pl.root_slot >= 0 && pl.root_slot < pl.nslots && pl.root_owner >= 0 && pl.root_owner < nranks);
+    std::vector<char> have(pl.nslots, 0);
+    for (int i = 0; i < pl.nlcl; ++i) have[i] = 1;
+    for (const int s : pl.my_root_slots) { REQUIRE(s >= 0 && s < pl.nslots); have[s] = 1; }
+    int prev = -1;
+    for (const auto& st : pl.steps) {
+      REQUIRE(st.level > prev);
+      prev = st.level;
+      REQUIRE(st.nodes.size() % 3 == 0);
+      for (size_t j = 0; j < st.nodes.size(); j += 3) {
+        for (int k = 0; k < 3; ++k) REQUIRE(st.nodes[j+k] >= 0 && st.nodes[j+k] < pl.nslots);
+        REQUIRE(have[st.nodes[j+1]] && have[st.nodes[j+2]] && ! have[st.nodes[j]]);
+      }
+      for (size_t j = 0; j < st.nodes.size(); j += 3) have[st.nodes[j]] = 1;
+      for (const int s : st.out_slots) REQUIRE(s >= 0 && s < pl.nslots && have[s]);
+      for (const int s : st.in_slots) { REQUIRE(s >= 0 && s < pl.nslots && ! have[s]); have[s] = 1; }
+      for (const auto* ml : {&st.out_msgs, &st.in_msgs}) {
+        const size_t n = ml == &st.out_msgs ? st.out_slots.size() : st.in_slots.size();
+        int at = 0, last_peer = -1;
+        for (const auto& m : *ml) {
+          REQUIRE(m.peer > last_peer && m.peer < nranks && m.peer != me && m.first == at && m.count > 0);
+          last_peer = m.peer;
+          at += m.count;
+        }
+        REQUIRE(at == (int) n);
+      }
+    }
+    if (pl.root_owner == me) REQUIRE(have[pl.root_slot]);
+  }
+  for (int a = 0; a < nranks; ++a) {
+    REQUIRE(pls[a].root_owner == pls[0].root_owner);
+    for (const auto& st : pls[a].steps)
+      for (const auto& m : st.out_msgs) {  // a -> m.peer at st.level: the peer expects exactly that
+        int found = 0;
+        for (const auto& sb : pls[m.peer].steps)
+          if (sb.level == st.level)
+            for (const auto& mb : sb.in_msgs) if (mb.peer == a) { REQUIRE(mb.count == m.count); ++found; }
+        REQUIRE(found == 1);
+      }
+    for (const auto& st : pls[a].steps)
+      for (const auto& m : st.in_msgs) {
+        int found = 0;
+        for (const auto& sb : pls[m.peer].steps)
+          if (sb.level == st.level)
+            for (const auto& mb : sb.out_msgs) if (mb.peer == a) ++found;
+        REQUIRE(found == 1);
+      }
   }
 }
 
@@ -148,6 +220,11 @@ int main () {
                               nc, P, pr, imb, tile, micro, cut);
                 check(t, nc, P, o, ctx);
                 ++ncase;
+                if (P > 1 && (cut == 2 || ! micro) && (tile == 3 || tile == 128)) {
+                  check_level(t, nc, P, o, false, ctx);
+                  check_level(t, nc, P, o, true, ctx);
+                  ncase += 2;
+                }
               }
         }
     }

@@ -190,6 +190,64 @@ def down_stage(stage, md, l2r, r2l, prefer=False):
                     l2r[lb, cell], l2r[lb + 2, cell] = qlo, qhi
 
 
+def level_up_nodes(step, data, ops, zero_init=False):
+    """Level mode, mirrors level_up_kernel: the nodes a rank owns above its pure subtrees."""
+    for me, c0, c1 in step["nodes"]:
+        data[:, me] = _comb(ops, data[:, c0], data[:, c1], zero_init)
+
+
+def level_down_nodes(step, md, l2r, r2l, prefer=False):
+    """Mirrors qlt_level_down_kernel."""
+    for me, c0, c1 in step["nodes"]:
+        rho0, rho1 = l2r[0, c0], l2r[0, c1]
+        for ti, pt in enumerate(md["trcr2prob"]):
+            pt = int(pt)
+            lb, rb = md["trcr2bl2r"][ti], md["trcr2br2l"][ti]
+            sp = bool(pt & SHAPEPRESERVE)
+            t_only = bool(pt & CONSISTENT) and not sp
+            of = 1 if (sp or (pt & CONSISTENT)) else 0
+            recs = []
+            for c in (c0, c1):
+                r = np.zeros(3)
+                if sp:
+                    r[:] = [l2r[lb + f, c] for f in range(3)]
+                else:
+                    r[1] = l2r[lb + of, c]
+                recs.append(r)
+            qlo = qhi = 0.0
+            if t_only:
+                qlo, qhi = r2l[rb + 1, me], r2l[rb + 2, me]
+            x0, x1 = _solve(pt, rho0 + rho1, recs[0] + recs[1], r2l[rb, me], rho0, recs[0], rho1, recs[1],
+                            qlo, qhi, prefer)
+            for c, x in ((c0, x0), (c1, x1)):
+                r2l[rb, c] = x
+                if t_only:
+                    r2l[rb + 1, c], r2l[rb + 2, c] = qlo, qhi
+                    l2r[lb, c], l2r[lb + 2, c] = qlo, qhi
+
+
+class Mailbox:
+    """In-process stand-in for point-to-point messages between rank THREADS: put never blocks,
+    get waits. Keys are (src, dst, tag)."""
+
+    def __init__(self):
+        import threading
+        self.cv = threading.Condition()
+        self.box = {}
+
+    def put(self, key, arr):
+        with self.cv:
+            assert key not in self.box, key
+            self.box[key] = np.array(arr, copy=True)
+            self.cv.notify_all()
+
+    def get(self, key, timeout=30):
+        with self.cv:
+            if not self.cv.wait_for(lambda: key in self.box, timeout):
+                raise RuntimeError("no message %r" % (key,))
+            return self.box.pop(key)
+
+
 class RankState:
     """One rank's buffers and plan; the exchange is supplied by the caller."""
 
@@ -200,6 +258,7 @@ class RankState:
         self.l2r = np.zeros((self.l2rndps, S))
         self.r2l = np.zeros((self.r2lndps, S))
         self.ops = field_ops(md, self.l2rndps)
+        self.owns_root = True  # level mode: set by the caller (plan["root_owner"] == its rank)
 
     def set(self, rhom, Qm, Qm_min, Qm_max, Qm_prev):
         n = len(rhom)
@@ -259,6 +318,31 @@ class RankState:
         if len(self.plan["top"]):
             for ts, ls in zip(self.plan["my_top_slots"], self.plan["my_root_slots"]):
                 self.r2l[:, ls] = self.r2l[:, ts]
+        for st in reversed(self.plan["local"]):
+            down_stage(st, self.md, self.l2r, self.r2l, self.prefer)
+
+    # ---- level mode (plan["level_mode"]): xch(tag, sends=[(peer, array)], recvs=[(peer, count)])
+    # -> received arrays [count][nfields], in the order of recvs
+    def _level_exchange(self, step, down, data, xch):
+        send_slots, recv_slots = (step["in_slots"], step["out_slots"]) if down else (step["out_slots"], step["in_slots"])
+        send_msgs, recv_msgs = (step["in_msgs"], step["out_msgs"]) if down else (step["out_msgs"], step["in_msgs"])
+        if not len(send_msgs) and not len(recv_msgs):
+            return
+        sends = [(int(p), data[:, send_slots[f:f + c]].T.copy()) for p, f, c in send_msgs]
+        got = xch(("down" if down else "up", int(step["level"])), sends, [(int(p), int(c)) for p, f, c in recv_msgs])
+        for (p, f, c), a in zip(recv_msgs, got):
+            data[:, recv_slots[f:f + c]] = np.asarray(a).reshape(c, data.shape[0]).T
+
+    def run_level_mode(self, xch):
+        """QLT::run's level-mode branch after the local leaves->root stages."""
+        for step in self.plan["steps"]:
+            level_up_nodes(step, self.l2r, self.ops)
+            self._level_exchange(step, False, self.l2r, xch)
+        if self.owns_root:
+            root_compute(self.md, int(self.plan["root_slot"]), self.l2r, self.r2l)
+        for step in reversed(self.plan["steps"]):
+            self._level_exchange(step, True, self.r2l, xch)
+            level_down_nodes(step, self.md, self.l2r, self.r2l, self.prefer)
         for st in reversed(self.plan["local"]):
             down_stage(st, self.md, self.l2r, self.r2l, self.prefer)
 

@@ -110,6 +110,80 @@ def test_apex_tile_shape(ca):
     assert ca.Tree.make_1d(64, 1).plan(64, 0, 1, 0)["apex"] is None  # single rank: no top at all
 
 
+def run_level_plan(ca, nc, P, full_tree, types, v, partial):
+    """Level mode with P rank threads and an in-process mailbox; every rank plans from its own
+    (pruned, if partial) tree."""
+    import threading
+    box = plan_exec.Mailbox()
+    out = np.zeros_like(v.Qm)
+    errs = []
+
+    def rank_main(r):
+        try:
+            tree = full_tree.prune(r) if partial else full_tree
+            q = ca.QLT(planning_parallel(ca, r, P), nc, tree)
+            for t in types:
+                q.declare_tracer(t, 0)
+            q.end_tracer_declarations()
+            pl = q.plan()
+            assert pl["level_mode"] and not pl["top"] and pl["apex"] is None
+            st = plan_exec.RankState(pl, q.metadata())
+            st.owns_root = pl["root_owner"] == r
+            g = q.get_owned_glblcells()
+            st.set(v.rhom[g], v.Qm[:, g], v.Qm_min[:, g], v.Qm_max[:, g], v.Qm_prev[:, g])
+            st.up_local()
+
+            def xch(tag, sends, recvs):
+                for peer, a in sends:
+                    box.put((r, peer, tag), a)
+                return [box.get((peer, r, tag)) for peer, _ in recvs]
+            st.run_level_mode(xch)
+            out[:, g] = st.get(len(g))
+        except Exception as e:  # noqa: BLE001
+            import traceback
+            errs.append("rank %d: %s" % (r, traceback.format_exc()))
+    th = [threading.Thread(target=rank_main, args=(r,)) for r in range(P)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, "\n".join(errs)
+    return out
+
+
+@pytest.mark.parametrize("partial", [False, True])
+@pytest.mark.parametrize("nc,P,pseudorandom,imbalanced", [
+    (2, 2, False, False), (24, 2, False, False), (60, 3, False, True), (64, 8, False, False),
+    (56, 8, True, False), (40, 4, True, True), (300, 7, False, True), (200, 5, True, False)])
+def test_level_mode_matches_oracle(ca, oracle, nc, P, pseudorandom, imbalanced, partial, monkeypatch):
+    """Partial caller trees (tree::Node::level) and scattered ownership: pure subtrees by tiles, the
+    rest of a rank's nodes level by level with point-to-point messages -- the same bits as the
+    oracle's single-rank tree."""
+    monkeypatch.setenv("CEDR_HIP_TILE_LEAVES", "8")
+    if not partial:
+        monkeypatch.setenv("CEDR_HIP_EXCHANGE", "2")  # a full tree: level mode has to be asked for
+    trs = R.tracers_vector()[:12]
+    types = [t.problem_type for t in trs]
+    v = R.make_values(trs, nc, seed=5*nc + P)
+    want = common.run_oracle_qlt(oracle, (False, imbalanced), nc, 1, types, v)
+    got = run_level_plan(ca, nc, P, ca.Tree.make_1d(nc, P, pseudorandom, imbalanced), types, v, partial)
+    assert np.array_equal(got, want)
+
+
+def test_level_mode_is_chosen_for_scattered_ownership(ca):
+    """The automatic rule: contiguous ownership keeps the one all-gather, pseudorandom ownership of
+    a tree big enough for it to matter goes level by level; every rank decides alike."""
+    nc, P = 100000, 4
+    for pr, want in ((False, False), (True, True)):
+        tree = ca.Tree.make_1d(nc, P, pr, False)
+        modes = {tree.plan(nc, r, P, 0)["level_mode"] for r in range(P)}
+        assert modes == {want}
+    pl = ca.Tree.make_1d(nc, P, True, False).prune(1).plan(nc, 1, P, 0)
+    assert pl["level_mode"]
+    # a pruned tree is O(cells/ranks + depth)
+    assert ca.Tree.make_1d(nc, P).prune(2).nnodes() < 2*nc//P + 64
+
+
 @pytest.mark.parametrize("tile", [2, 3, 5, 64, 256])
 def test_plan_invariants(ca, tile):
     nc = 1000

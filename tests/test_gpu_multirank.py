@@ -42,6 +42,19 @@ def test_rccl_single_rank(gpu, oracle):
     assert common.rel_per_tracer(got, want).max() <= 1e-13
 
 
+def test_rccl_point_to_point_group(gpu):
+    """The level-mode transport on RCCL: ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd. One
+    device takes one rank, so the round is a message to self; it still runs the real entry points."""
+    ca = gpu
+    par = ca.Parallel.rccl(ca.Parallel.rccl_unique_id(), 0, 1)
+    a = np.arange(1000, dtype=np.float64) * 0.5
+    src, dst = ca.DeviceArray.from_numpy(a), ca.DeviceArray.from_numpy(np.zeros(1000))
+    assert par.exchange([(0, src.ptr, 1000, True), (0, dst.ptr, 1000, False)]) == 0
+    ca.synchronize()
+    assert np.array_equal(dst.numpy(), a)
+    assert par.exchange([]) == 0
+
+
 def _bench(args, timeout=600):
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True,
                          timeout=timeout, cwd=ROOT)

@@ -153,3 +153,82 @@ def test_bfb_allreduce_ranks_as_threads(gpu, oracle, nranks, ncell, transpose):
     T.run_ranks(nranks, body)
     for r in range(nranks):
         assert np.array_equal(got[r], want), r
+
+
+# ---- level mode: partial caller trees (tree::Node::level) and scattered ownership
+@pytest.mark.parametrize("nranks,ncells,pseudorandom,imbalanced", [
+    (2, 24, False, False), (3, 111, False, True), (4, 1000, False, False), (8, 1000, True, False),
+    (8, 5000, False, False), (8, 8, False, False), (5, 1024, True, True)])
+@pytest.mark.parametrize("partial", [False, True])
+def test_qlt_level_mode_ranks_as_threads_bitwise(gpu, oracle, nranks, ncells, pseudorandom, imbalanced, partial,
+                                                 monkeypatch):
+    """Every rank passes only its part of the tree (partial), or the full tree with the per-level
+    exchange forced: pure subtrees by the tile kernels, the rest level by level with point-to-point
+    messages (reference cedr_qlt.cpp:618-640) -- the same bits as the single-rank oracle."""
+    if not partial:
+        monkeypatch.setenv("CEDR_HIP_EXCHANGE", "2")
+    trs = R.tracers_vector()
+    types = [t.problem_type for t in trs]
+    v = R.make_values(trs, ncells, seed=99 + ncells)
+    want = common.run_oracle_qlt(oracle, (False, imbalanced), ncells, 1, types, v, False)
+    got = T.run_qlt(gpu, nranks, ncells, types, v, False, pseudorandom, imbalanced, nrepeat=2, partial=partial,
+                    want_level_mode=True)
+    assert np.array_equal(got, want)
+    assert R.check(trs, v, got, False, verbose=False)[0] == 0
+
+
+def test_qlt_level_mode_larger_scattered(gpu, oracle):
+    """Pseudorandom ownership at a size where the automatic rule picks level mode by itself
+    (the all-gather would hand every rank the whole tree): 6 ranks, 120k cells, 3 tracers."""
+    nranks, ncells = 6, 120000
+    trs = R.tracers_vector()[:3]
+    types = [t.problem_type for t in trs]
+    v = R.make_values(trs, ncells, seed=6)
+    want = common.run_oracle_qlt(oracle, (False, False), ncells, 1, types, v, False)
+    got = T.run_qlt(gpu, nranks, ncells, types, v, False, True, False, want_level_mode=True)
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("nranks,ncell", [(2, 24), (3, 1000), (8, 1000), (8, 8)])
+@pytest.mark.parametrize("transpose", [False, True])
+def test_bfb_level_mode_ranks_as_threads(gpu, oracle, nranks, ncell, transpose):
+    """BfbTreeAllReducer over partial trees: the root's owner broadcasts the result."""
+    ca = gpu
+    nfield = 5
+    rng = np.random.default_rng(ncell + nranks)
+    glob = rng.random((ncell, nfield))
+    lay = lambda a: np.ascontiguousarray(a.T if transpose else a).ravel()
+    want = oracle.bfb_allreduce(oracle.Tree.make_1d(ncell, 1, False, False), ncell, 1, nfield, transpose,
+                                [lay(glob)])[0]
+    got = [None] * nranks
+
+    def body(rank, comm):
+        par = comm.parallel(ca, rank)
+        tree = ca.Tree.make_1d(ncell, nranks, False, False).prune(rank)
+        mine = _bfb_local_leaves(tree, ncell, rank)
+        b = ca.BfbTreeAllReducer(par, tree, ncell, nfield)
+        assert b.nlocal() == len(mine)
+        sd = ca.DeviceArray.from_numpy(lay(glob[mine]))
+        rd = ca.DeviceArray(nfield)
+        for _ in range(2):
+            b.allreduce(sd, rd, transpose)
+        ca.synchronize()
+        got[rank] = rd.numpy()
+    T.run_ranks(nranks, body)
+    for r in range(nranks):
+        assert np.array_equal(got[r], want), r
+
+
+def test_level_mode_needs_point_to_point(gpu):
+    """A transport without the exchange callback runs all-gather plans only: a level-mode plan
+    fails with a message, not with wrong numbers."""
+    ca = gpu
+    bad = lambda *a: 1
+    tree = ca.Tree.make_1d(64, 2).prune(0)
+    q = ca.QLT(ca.Parallel.callbacks(0, 2, bad, bad), 64, tree)
+    q.declare_tracer(7, 0)
+    q.end_tracer_declarations()
+    q.finish_setup()
+    assert q.plan()["level_mode"]
+    with pytest.raises(ca.CedrError, match="point-to-point"):
+        q.run()

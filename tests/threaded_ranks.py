@@ -17,6 +17,9 @@ class ThreadComm:
         self.P = nranks
         self.bar = threading.Barrier(nranks, timeout=timeout)
         self.slots = [None] * nranks
+        self.cv = threading.Condition()
+        self.fifo = {}
+        self.timeout = timeout
 
     def allgather(self, rank, x):
         self.slots[rank] = np.array(x, dtype=np.float64)
@@ -34,9 +37,28 @@ class ThreadComm:
         self.bar.wait()
         return out
 
+    def exchange(self, rank, sends, recvs):
+        """One round of point-to-point messages (level mode): FIFO per (source, destination) --
+        the rounds come in the same order on both sides, with at most one message per pair."""
+        for peer, a in sends:
+            with self.cv:
+                self.fifo.setdefault((rank, peer), []).append(np.array(a, dtype=np.float64))
+                self.cv.notify_all()
+        out = []
+        for peer, n in recvs:
+            with self.cv:
+                ok = self.cv.wait_for(lambda: self.fifo.get((peer, rank)) or self.bar.broken, self.timeout)
+                if not ok or self.bar.broken:
+                    raise threading.BrokenBarrierError()
+                a = self.fifo[(peer, rank)].pop(0)
+            assert a.size == n, (a.size, n)
+            out.append(a)
+        return out
+
     def parallel(self, ca, rank):
-        return ca.Parallel.host_staged(rank, self.P, lambda x: self.allgather(rank, x),
-                                       lambda x: self.allreduce(rank, x))
+        return ca.Parallel.host_staged_p2p(rank, self.P, lambda x: self.allgather(rank, x),
+                                           lambda x: self.allreduce(rank, x),
+                                           lambda sends, recvs: self.exchange(rank, sends, recvs))
 
 
 def run_ranks(nranks, body, timeout=600):
@@ -51,6 +73,8 @@ def run_ranks(nranks, body, timeout=600):
         except BaseException as e:  # noqa: BLE001 -- reported to the caller below
             errs[r] = e
             comm.bar.abort()
+            with comm.cv:
+                comm.cv.notify_all()
     ts = [threading.Thread(target=wrap, args=(r,)) for r in range(nranks)]
     for t in ts:
         t.start()
@@ -64,17 +88,23 @@ def run_ranks(nranks, body, timeout=600):
     return res
 
 
-def run_qlt(ca, nranks, ncells, types, v, prefer=False, pseudorandom=False, imbalanced=False, nrepeat=1):
-    """Global arrays in, global result out; every rank owns what Tree.make_1d gives it."""
+def run_qlt(ca, nranks, ncells, types, v, prefer=False, pseudorandom=False, imbalanced=False, nrepeat=1,
+            partial=False, want_level_mode=None):
+    """Global arrays in, global result out; every rank owns what Tree.make_1d gives it.
+    partial: every rank passes only its part of the tree (tree::Node::level)."""
     out = np.zeros_like(v.Qm)
 
     def body(rank, comm):
         tree = ca.Tree.make_1d(ncells, nranks, pseudorandom, imbalanced)
+        if partial:
+            tree = tree.prune(rank)
         q = ca.QLT(comm.parallel(ca, rank), ncells, tree, prefer)
         for t in types:
             q.declare_tracer(t, 0)
         q.end_tracer_declarations()
         q.finish_setup()
+        if want_level_mode is not None:
+            assert q.plan()["level_mode"] == want_level_mode
         g = q.get_owned_glblcells()
         d = [ca.DeviceArray.from_numpy(a) for a in
              (v.rhom[g], v.Qm[:, g], v.Qm_min[:, g], v.Qm_max[:, g], v.Qm_prev[:, g])]
