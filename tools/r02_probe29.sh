@@ -1,0 +1,12 @@
+#!/bin/bash
+# Up sweep: streaming (nontemporal) stores for the tile outputs against the product build.
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+export TMPDIR=/tmp
+cd "$R"
+O=gpurun_out/r02p29
+mkdir -p $O
+V=$R/compose_amd/variants
+for v in base up_ntstore base up_ntstore; do
+  if [ $v = base ]; then unset CEDR_HIP_LIB; else export CEDR_HIP_LIB=$V/$v.so; fi
+  timeout -k 10 300 python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --check > $O/$v.json 2> $O/b.err && { echo "== $v"; python3 tests/showbench.py $O/$v.json | grep "value\|tree_up_kernel *launch"; }
+done
