@@ -44,9 +44,11 @@ def parse():
     ap.add_argument("--cpu-cells", type=int, default=0,
                     help="cells of the CPU-baseline run (same tracer count); 0 = the configuration itself")
     ap.add_argument("--check", action="store_true", help="verify properties of the results")
-    ap.add_argument("--overlap", action="store_true",
-                    help="QLT and CAAS on two concurrent streams instead of back to back on one (measured on "
-                         "one GPU: 2 %% at 1.5M cells, 10 %% at the 187.5k-cell shard of an 8-GPU run). With N > 1 "
+    ap.add_argument("--overlap", nargs="?", const="start", default=None, choices=["start", "down"],
+                    help="QLT and CAAS on two concurrent streams instead of back to back on one: 'start' = both "
+                         "begin together (measured on one GPU: 2-3 %% at 1.5M cells, 10 %% at the 187.5k-cell "
+                         "shard of an 8-GPU run); 'down' = CAAS::run begins when QLT::run reaches its first-stage "
+                         "root->leaves sweep (fp64-issue bound, so the memory-bound CAAS kernels fit beside it). With N > 1 "
                          "the two CDRs still share ONE communicator, whose collectives the library orders "
                          "with events across streams; the default for N > 1 stays one stream.")
     ap.add_argument("--serial", action="store_true", help="(default now; kept for older command lines)")
@@ -316,8 +318,12 @@ def main():
         if world > 1:
             dist.barrier()
 
+    down_ev = qlt.sweep_down_event() if (streams and a.overlap == "down") else None
+
     def step():
         qlt.run()
+        if down_ev:  # CAAS::run starts when QLT::run reaches its first-stage root->leaves sweep
+            ca.stream_wait_event(streams[1].cuda_stream, down_ev)
         caas.run()
 
     for _ in range(a.warmup):

@@ -108,6 +108,8 @@ _SIGS = {
     "cedr_qlt_gci2lci": (C.c_int, [_vp, C.c_int]),
     "cedr_qlt_run": (C.c_int, [_vp]),
     "cedr_qlt_set_stream": (C.c_int, [_vp, _vp]),
+    "cedr_qlt_sweep_down_event": (_vp, [_vp]),
+    "cedr_stream_wait_event": (C.c_int, [_vp, _vp]),
     "cedr_qlt_get_device_op": (C.c_int, [_vp, C.POINTER(_QltDeviceOp)]),
     "cedr_qlt_set_rhom_bulk": (C.c_int, [_vp, _vp]),
     "cedr_qlt_set_Qm_bulk": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
@@ -636,9 +638,19 @@ class _CDR:
         self._stream = stream
 
 
+def stream_wait_event(stream, event):
+    """hipStreamWaitEvent(stream, event)."""
+    _chk(lib().cedr_stream_wait_event(stream, event), "stream_wait_event")
+
+
 class QLT(_CDR):
     """cedr::qlt::QLT (reference cedr/cedr_qlt.hpp:129-197)."""
     _pfx = "cedr_qlt_"
+
+    def sweep_down_event(self):
+        """hipEvent_t run() records just before its first-stage root->leaves sweep (fp64-issue bound): another
+        stream that waits for it runs memory-bound work side by side with that sweep."""
+        return _handle(lib().cedr_qlt_sweep_down_event(self.h), "sweep_down_event")
 
     def __init__(self, parallel, ncells, tree, prefer_mass_con_to_bounds=False):
         self.p, self.tree = parallel, tree

@@ -224,6 +224,10 @@ int cedr_qlt_get_owned_glblcells (void* h, long* gcis) {
 int cedr_qlt_gci2lci (void* h, int gci) { CEDR_TRY return Q(h).gci2lci(gci); CEDR_CATCH(-1) }
 int cedr_qlt_run (void* h) { CEDR_TRY Q(h).run(); return 0; CEDR_CATCH(-1) }
 int cedr_qlt_set_stream (void* h, cedr_stream_t s) { Q(h).set_stream(s); return 0; }
+void* cedr_qlt_sweep_down_event (void* h) { CEDR_TRY return Q(h).sweep_down_event(); CEDR_CATCH(nullptr) }
+int cedr_stream_wait_event (cedr_stream_t s, void* ev) {
+  return static_cast<int>(hipStreamWaitEvent(static_cast<hipStream_t>(s), static_cast<hipEvent_t>(ev), 0));
+}
 int cedr_qlt_get_device_op (void* h, cedr_qlt_device_op* out) {
   const auto& o = Q(h).get_device_op();
   out->l2r_data = o.l2r_data; out->r2l_data = o.r2l_data; out->stride = o.stride;

@@ -43,6 +43,8 @@ struct QLTHip::Impl {
   Real* b_out = nullptr;
   bool bound_rows = false;  // the kernels read / write the caller's rows directly
   std::vector<Int> packed_tracers;  // caller indices of the t-only tracers
+  hipEvent_t down_ev = nullptr;     // see QLTHip::sweep_down_event
+  ~Impl () { if (down_ev) (void) hipEventDestroy(down_ev); }
 };
 
 // ---- MetaData: reference cedr_qlt.cpp:85-157, cedr_qlt_inl.hpp:101-117 ----
@@ -284,6 +286,11 @@ const QLTHip::DeviceOp& QLTHip::get_device_op () { return o; }
 
 void QLTHip::set_stream (hipStream_t stream) { d_->stream = stream; }
 
+hipEvent_t QLTHip::sweep_down_event () {
+  if ( ! d_->down_ev) cedr_hip_check(hipEventCreateWithFlags(&d_->down_ev, hipEventDisableTiming));
+  return d_->down_ev;
+}
+
 void QLTHip::set_rhom_bulk (const Real* rhom) {
   cedr_throw_if( ! o.l2r_data, "finish_setup was not called");
   cedr_k_check(cedr_hip_qlt_set_rhom(o.stride, nlclcells(), rhom, o.l2r_data, d_->stream));
@@ -403,6 +410,7 @@ void QLTHip::run () {
   const auto& loc = eng_->local_stages();
   for (size_t i = loc.size(); i > 0; --i) {
     const bool rows = rows_mode && i == 1;
+    if (i == 1 && d.down_ev) cedr_hip_check(hipEventRecord(d.down_ev, s));
     cedr_k_check(cedr_hip_qlt_down_rows(&d.lay, &loc[i-1]->h, d.l2r, d.r2l,
                                         rows ? d.in_rows.data() : nullptr,
                                         rows ? d.out_rows.data() : nullptr, nlclcells(), s));

@@ -13,6 +13,8 @@
 
 typedef struct ihipStream_t* hipStream_t;
 
+typedef struct ihipEvent_t* hipEvent_t;
+
 namespace cedr {
 namespace engine { class TreeEngine; }
 namespace qlt {
@@ -96,6 +98,11 @@ public:
   // ---- additions of this build ----
   // All work is enqueued on this stream (default: the null stream).
   void set_stream(hipStream_t stream);
+  // An event run() records on its stream just before the first-stage root->leaves sweep, the one
+  // long kernel of a run that is bound by fp64 issue and leaves HBM bandwidth unused: a caller
+  // with independent memory-bound work (CAAS on other tracers, a halo copy) lets another stream
+  // wait for it (hipStreamWaitEvent) so that the two run side by side. Created on first call.
+  hipEvent_t sweep_down_event();
   // Bulk forms of the DeviceOp calls over all local cells; device arrays laid
   // out [tracer][cell] in caller tracer order (rhom: [cell]).
   void set_rhom_bulk(const Real* rhom);

@@ -291,6 +291,12 @@ int cedr_qlt_get_owned_glblcells(void* qlt, long* gcis);
 int cedr_qlt_gci2lci(void* qlt, int gci); /* < 0 on error */
 int cedr_qlt_run(void* qlt);
 int cedr_qlt_set_stream(void* qlt, cedr_stream_t stream);
+/* A hipEvent_t that run() records on its stream just before its first-stage root->leaves sweep (the
+ * long kernel of a run that is bound by fp64 issue, not by HBM): let another stream wait for it
+ * (cedr_stream_wait_event = hipStreamWaitEvent) to run independent memory-bound work, e.g. CAAS,
+ * side by side with that sweep. Owned by the QLT. */
+void* cedr_qlt_sweep_down_event(void* qlt);
+int cedr_stream_wait_event(cedr_stream_t stream, void* event);
 /* DeviceOp for C callers: the values a device kernel needs to do set/get itself. */
 typedef struct {
   double* l2r_data; double* r2l_data; int64_t stride;

@@ -236,3 +236,46 @@ def test_tight_buffers(gpu, oracle):
     got = common.run_hip_qlt(ca, q, v)
     want = common.run_oracle_qlt(oracle, (False, False), n, 1, types, v)
     assert np.array_equal(got, want)
+
+
+def test_sweep_down_event_orders_a_second_stream(gpu, oracle):
+    """QLT::sweep_down_event: CAAS on a second stream starts when QLT::run reaches its first-stage
+    root->leaves sweep. Both results must be what the two runs give one after the other."""
+    import torch
+    ca = gpu
+    nc = 20000
+    trs = R.tracers_vector()[:12]
+    types = [t.problem_type for t in trs]
+    v = R.make_values(trs, nc, seed=31)
+    want = common.run_oracle_qlt(oracle, (False, False), nc, 1, types, v)
+    q = common.make_hip_qlt(ca, ca.Tree.make_1d(nc, 1), nc, types)
+    ctr = R.caas_tracers(trs)
+    ctypes_ = [t.problem_type for t in ctr]
+    cv = R.make_values(ctr, nc, seed=32)
+    cwant, _ = common.run_oracle_caas(oracle, [nc], ctypes_, cv)
+    c = ca.CAAS(ca.Parallel.self_(), nc)
+    for t in ctypes_:
+        c.declare_tracer(t, 0)
+    c.end_tracer_declarations()
+    c.finish_setup()
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    q.set_stream(sa.cuda_stream)
+    c.set_stream(sb.cuda_stream)
+    ev = q.sweep_down_event()
+    assert ev and q.sweep_down_event() == ev
+    d = [ca.DeviceArray.from_numpy(a) for a in (v.rhom, v.Qm, v.Qm_min, v.Qm_max, v.Qm_prev)]
+    e = [ca.DeviceArray.from_numpy(a) for a in (cv.rhom, cv.Qm, cv.Qm_min, cv.Qm_max, cv.Qm_prev)]
+    q.set_rhom(d[0])
+    c.set_rhom(e[0])
+    for _ in range(3):
+        q.set_Qm(d[1], d[2], d[3], d[4])
+        c.set_Qm(e[1], e[2], e[3], e[4])
+        q.run()
+        ca.stream_wait_event(sb.cuda_stream, ev)
+        c.run()
+    qo, co = ca.DeviceArray(v.Qm.size), ca.DeviceArray(cv.Qm.size)
+    q.get_Qm(qo)
+    c.get_Qm(co)
+    ca.synchronize()
+    assert np.array_equal(qo.numpy(v.Qm.shape), want)
+    assert common.rel_per_tracer(co.numpy(cv.Qm.shape), cwant).max() <= 1e-13
