@@ -295,23 +295,26 @@ static Plan build_level_mode (const tree::FlatTree& t, const int32_t me, const i
   p.root_slot = b.slot[0] >= 0 ? b.slot[0] : b.next_slot++;
   p.nslots = b.next_slot;
 
-  // Steps. (peer, slot) lists in DFS order, then grouped by peer with a stable sort.
-  struct Ev { int32_t level, peer, slot; };
+  // Steps: (peer, slot) lists grouped by level and peer.
+  struct Ev { int32_t level, peer, slot, node; };
   std::vector<Ev> outs, ins;
   std::vector<std::pair<int32_t,int32_t> > mine;  // (level, node)
   for (int32_t n = 0; n < nn; ++n) {
     if (rank[n] != me) continue;
     const int32_t par = t.parent[n];
-    if (par >= 0 && rank[par] != me) outs.push_back(Ev{lvl[n], rank[par], b.slot[n]});
+    if (par >= 0 && rank[par] != me) outs.push_back(Ev{lvl[n], rank[par], b.slot[n], n});
     if (pure[n]) continue;
     mine.push_back(std::make_pair(lvl[n], n));
     for (Int i = 0; i < 2; ++i) {
       const int32_t c = t.kid(n, i);
-      if (rank[c] != me) ins.push_back(Ev{lvl[c], rank[c], b.slot[c]});
+      if (rank[c] != me) ins.push_back(Ev{lvl[c], rank[c], b.slot[c], c});
     }
   }
+  // Within a message the records are in the nodes' own DFS (pre-order) order -- NOT their parents':
+  // a kid of a node can come after a same-level kid of one of that node's descendants.
   const auto by_level_peer = [] (const Ev& a, const Ev& c) {
-    return a.level != c.level ? a.level < c.level : a.peer < c.peer;
+    if (a.level != c.level) return a.level < c.level;
+    return a.peer != c.peer ? a.peer < c.peer : a.node < c.node;
   };
   std::stable_sort(outs.begin(), outs.end(), by_level_peer);
   std::stable_sort(ins.begin(), ins.end(), by_level_peer);
@@ -371,8 +374,9 @@ Plan build (const tree::FlatTree& t, int32_t my_rank, int32_t nranks,
   if (nranks > 1 && (partial || opt.exchange == 2)) return build_level_mode(t, my_rank, nranks, leaf_slot, opt);
 
   // own[n]: the rank owning every leaf below n, or -1 if more than one does.
-  std::vector<int32_t> own(nn, -1);
+  std::vector<int32_t> own(nn, -1), rk(t.rank.begin(), t.rank.end());
   int64_t ncells = 0;
+  bool pinned_inside = false;  // a node pinned to another rank than the one owning everything below it
   for (const Int n : tree::post_order(t)) {
     if (t.nkids[n] == 0) {
       cedr_throw_if(t.rank[n] < 0 || t.rank[n] >= nranks, "leaf rank out of range");
@@ -383,8 +387,14 @@ Plan build (const tree::FlatTree& t, int32_t my_rank, int32_t nranks,
                     << t.nkids[n] << " kids.");
       const int32_t a = own[t.kid0[n]], b = own[t.kid1[n]];
       own[n] = (a >= 0 && a == b) ? a : -1;
+      if (rk[n] < 0) rk[n] = rk[t.kid0[n]];
+      if (own[n] >= 0 && rk[n] != own[n]) pinned_inside = true;
     }
   }
+  // The replicated-top design takes ownership from the leaves. A caller that pins a node inside a
+  // single-rank subtree to ANOTHER rank (tree::Node::rank) wants that node computed there; level
+  // mode does exactly that (every rank sees the same full tree here, so all decide alike).
+  if (pinned_inside && opt.exchange == 0 && nranks > 1) return build_level_mode(t, my_rank, nranks, leaf_slot, opt);
 
   // Boundary roots = roots of maximal single-rank subtrees, in DFS order.
   std::vector<int32_t> broots;

@@ -170,6 +170,86 @@ def test_level_mode_matches_oracle(ca, oracle, nc, P, pseudorandom, imbalanced, 
     assert np.array_equal(got, want)
 
 
+def run_tree_plan(ca, nc, P, tree, types, v, mode, partial):
+    """One tree on P ranks through the numpy plan executor: mode 1 = all-gather + replicated top,
+    2 = level mode; partial: every rank plans from its pruned tree (then always level mode)."""
+    import threading
+    box = plan_exec.Mailbox()
+    out = np.zeros_like(v.Qm)
+    states, errs = [None] * P, []
+    for r in range(P):
+        q = ca.QLT(planning_parallel(ca, r, P), nc, tree.prune(r) if partial else tree)
+        for t in types:
+            q.declare_tracer(t, 0)
+        q.end_tracer_declarations()
+        pl = q.plan()
+        assert pl["level_mode"] == (mode == 2 or partial)
+        st = plan_exec.RankState(pl, q.metadata())
+        st.owns_root = pl["root_owner"] == r
+        g = q.get_owned_glblcells()
+        st.set(v.rhom[g], v.Qm[:, g], v.Qm_min[:, g], v.Qm_max[:, g], v.Qm_prev[:, g])
+        st.up_local()
+        states[r] = (q, st, g)
+    if mode == 1 and not partial:
+        allbuf = [st.send_records() for _, st, _ in states]
+        for q, st, g in states:
+            st.recv_records(allbuf)
+            st.top_and_down(st.plan["apex"] is not None)
+            out[:, g] = st.get(len(g))
+        return out
+
+    def rank_main(r):
+        try:
+            q, st, g = states[r]
+
+            def xch(tag, sends, recvs):
+                for peer, a in sends:
+                    box.put((r, peer, tag), a)
+                return [box.get((peer, r, tag)) for peer, _ in recvs]
+            st.run_level_mode(xch)
+            out[:, g] = st.get(len(g))
+        except Exception:  # noqa: BLE001
+            import traceback
+            errs.append("rank %d: %s" % (r, traceback.format_exc()))
+    th = [threading.Thread(target=rank_main, args=(r,)) for r in range(P)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, "\n".join(errs)
+    return out
+
+
+@pytest.mark.parametrize("kind,nleaf,P,how,pin", [
+    ("merge", 40, 2, "blocks", 0.0), ("merge", 333, 5, "blocks", 0.0), ("merge", 200, 4, "scattered", 0.0),
+    ("skew", 150, 3, "blocks", 0.0), ("chain", 60, 3, "blocks", 0.0), ("chain", 45, 4, "scattered", 0.0),
+    ("merge", 120, 4, "blocks", 0.3), ("skew", 90, 6, "scattered", 0.5)])
+def test_random_caller_trees_on_many_ranks(ca, oracle, kind, nleaf, P, how, pin, monkeypatch):
+    """Irregular caller trees (cedr_tree_caller.hpp:12-30) with block and scattered ownership, and
+    internal nodes pinned to ranks that own nothing below them: the all-gather path, level mode on
+    the full tree and level mode from per-rank partial trees all give the single-rank oracle's bits."""
+    import random_trees as RT
+    monkeypatch.setenv("CEDR_HIP_TILE_LEAVES", "8")
+    rng = np.random.default_rng(7 * nleaf + P)
+    root, kid0, kid1, rank, cell = RT.random_tree(rng, nleaf, kind)
+    rank = RT.assign_ranks(rng, nleaf, rank, P, how, pin)
+    trs = R.tracers_vector()[:12]
+    types = [t.problem_type for t in trs]
+    v = R.make_values(trs, nleaf, seed=nleaf)
+    want = RT.oracle_single_rank(oracle, root, kid0, kid1, cell, nleaf, types, v)
+    tree = ca.Tree.from_arrays(root, kid0, kid1, rank, cell)
+    # mode 0 = the planner's own choice: nodes pinned away from the rank that owns everything below
+    # them (pin > 0) make it pick level mode; the all-gather path takes ownership from the leaves
+    for mode, partial in ((0 if pin > 0 else 1, False), (2, False), (2, True)):
+        monkeypatch.setenv("CEDR_HIP_EXCHANGE", str(mode))
+        if partial:
+            monkeypatch.delenv("CEDR_HIP_EXCHANGE")
+        if mode == 0:
+            mode = 2
+        got = run_tree_plan(ca, nleaf, P, tree, types, v, mode, partial)
+        assert np.array_equal(got, want), (mode, partial)
+
+
 def test_level_mode_is_chosen_for_scattered_ownership(ca):
     """The automatic rule: contiguous ownership keeps the one all-gather, pseudorandom ownership of
     a tree big enough for it to matter goes level by level; every rank decides alike."""

@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 
 import common
+import random_trees
 import randomized as R
 
 pytestmark = pytest.mark.gpu
@@ -136,30 +137,6 @@ def test_qlt_bound_arrays_zero_copy(gpu, oracle, ncells, in_place):
     assert np.array_equal(got, want)
 
 
-def _random_tree(rng, nleaf, kind):
-    """Binary tree over nleaf leaves as arrays: 'merge' = repeatedly merge two adjacent
-    subtrees picked at random (bushy, irregular), 'chain' = left-deep caterpillar (depth
-    nleaf - 1: every stage of the plan sees a degenerate tile), 'skew' = merges biased
-    towards one end. Global cell ids are a random permutation of the leaves."""
-    kid0, kid1 = [-1] * nleaf, [-1] * nleaf
-    roots = list(range(nleaf))
-    while len(roots) > 1:
-        if kind == "chain":
-            i = 0
-        elif kind == "skew":
-            i = int(min(len(roots) - 2, rng.integers(0, max(1, len(roots) // 8))))
-        else:
-            i = int(rng.integers(0, len(roots) - 1))
-        kid0.append(roots[i]); kid1.append(roots[i + 1])
-        roots[i:i + 2] = [len(kid0) - 1]
-    n = len(kid0)
-    rank = np.full(n, -1, np.int32)
-    rank[:nleaf] = 0
-    cell = np.full(n, -1, np.int64)
-    cell[:nleaf] = rng.permutation(nleaf)
-    return roots[0], kid0, kid1, rank, cell
-
-
 @pytest.mark.parametrize("kind,nleaf", [("merge", 2), ("merge", 17), ("merge", 500), ("merge", 3001),
                                         ("chain", 3), ("chain", 200), ("chain", 1500),
                                         ("skew", 64), ("skew", 2000)])
@@ -168,7 +145,7 @@ def test_qlt_caller_trees_bitwise(gpu, oracle, kind, nleaf):
     bisection: irregular, very deep, skewed; global cell ids in random order."""
     ca = gpu
     rng = np.random.default_rng(1000 + nleaf)
-    root, kid0, kid1, rank, cell = _random_tree(rng, nleaf, kind)
+    root, kid0, kid1, rank, cell = random_trees.random_tree(rng, nleaf, kind)
     trs = R.tracers_vector()
     types = [t.problem_type for t in trs]
     v = R.make_values(trs, nleaf, seed=nleaf)

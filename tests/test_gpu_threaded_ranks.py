@@ -232,3 +232,52 @@ def test_level_mode_needs_point_to_point(gpu):
     assert q.plan()["level_mode"]
     with pytest.raises(ca.CedrError, match="point-to-point"):
         q.run()
+
+
+@pytest.mark.parametrize("kind,nleaf,nranks,how,pin", [
+    ("merge", 40, 2, "blocks", 0.0), ("merge", 3001, 5, "blocks", 0.0), ("merge", 800, 4, "scattered", 0.0),
+    ("skew", 1500, 3, "blocks", 0.0), ("chain", 300, 3, "blocks", 0.0), ("chain", 45, 4, "scattered", 0.0),
+    ("merge", 1200, 4, "blocks", 0.3), ("skew", 900, 6, "scattered", 0.5), ("merge", 20000, 8, "blocks", 0.0)])
+def test_qlt_random_caller_trees_ranks_as_threads(gpu, oracle, kind, nleaf, nranks, how, pin, monkeypatch):
+    """Irregular caller trees (cedr_tree_caller.hpp:12-30) on several ranks: block and scattered
+    ownership, internal nodes pinned to ranks that own nothing below them. The all-gather path
+    (or what the planner picks when nodes are pinned), level mode on the full tree, and level mode
+    from per-rank partial trees all give the single-rank oracle's bits."""
+    import random_trees as RT
+    ca = gpu
+    rng = np.random.default_rng(7 * nleaf + nranks)
+    root, kid0, kid1, rank, cell = RT.random_tree(rng, nleaf, kind)
+    rank = RT.assign_ranks(rng, nleaf, rank, nranks, how, pin)
+    trs = R.tracers_vector()
+    types = [t.problem_type for t in trs]
+    v = R.make_values(trs, nleaf, seed=nleaf)
+    want = RT.oracle_single_rank(oracle, root, kid0, kid1, cell, nleaf, types, v)
+    for mode, partial in ((0 if pin > 0 else 1, False), (2, False), (2, True)):
+        monkeypatch.setenv("CEDR_HIP_EXCHANGE", str(mode))
+        if partial:
+            monkeypatch.delenv("CEDR_HIP_EXCHANGE")
+        out = np.zeros_like(v.Qm)
+
+        def body(r, comm):
+            tree = ca.Tree.from_arrays(root, kid0, kid1, rank, cell)
+            if partial:
+                tree = tree.prune(r)
+            q = ca.QLT(comm.parallel(ca, r), nleaf, tree)
+            for t in types:
+                q.declare_tracer(t, 0)
+            q.end_tracer_declarations()
+            q.finish_setup()
+            assert q.plan()["level_mode"] == (mode != 1)
+            g = q.get_owned_glblcells()
+            d = [ca.DeviceArray.from_numpy(a) for a in
+                 (v.rhom[g], v.Qm[:, g], v.Qm_min[:, g], v.Qm_max[:, g], v.Qm_prev[:, g])]
+            q.set_rhom(d[0])
+            for _ in range(2):
+                q.set_Qm(d[1], d[2], d[3], d[4])
+                q.run()
+            od = ca.DeviceArray(len(types) * len(g))
+            q.get_Qm(od)
+            ca.synchronize()
+            out[:, g] = od.numpy((len(types), len(g)))
+        T.run_ranks(nranks, body)
+        assert np.array_equal(out, want), (mode, partial)
