@@ -172,7 +172,7 @@ def test_level_mode_matches_oracle(ca, oracle, nc, P, pseudorandom, imbalanced, 
 
 def run_tree_plan(ca, nc, P, tree, types, v, mode, partial):
     """One tree on P ranks through the numpy plan executor: mode 1 = all-gather + replicated top,
-    2 = level mode; partial: every rank plans from its pruned tree (then always level mode)."""
+    2 = level mode, 0 = whichever the planner picks; partial: every rank plans from its pruned tree (then always level mode)."""
     import threading
     box = plan_exec.Mailbox()
     out = np.zeros_like(v.Qm)
@@ -183,13 +183,19 @@ def run_tree_plan(ca, nc, P, tree, types, v, mode, partial):
             q.declare_tracer(t, 0)
         q.end_tracer_declarations()
         pl = q.plan()
-        assert pl["level_mode"] == (mode == 2 or partial)
+        if mode == 0:  # the planner's own choice; every rank must make the same one
+            chosen = pl["level_mode"] if r == 0 else chosen
+            assert pl["level_mode"] == chosen
+        else:
+            assert pl["level_mode"] == (mode == 2 or partial)
         st = plan_exec.RankState(pl, q.metadata())
         st.owns_root = pl["root_owner"] == r
         g = q.get_owned_glblcells()
         st.set(v.rhom[g], v.Qm[:, g], v.Qm_min[:, g], v.Qm_max[:, g], v.Qm_prev[:, g])
         st.up_local()
         states[r] = (q, st, g)
+    if mode == 0:
+        mode = 2 if chosen else 1
     if mode == 1 and not partial:
         allbuf = [st.send_records() for _, st, _ in states]
         for q, st, g in states:
@@ -244,8 +250,6 @@ def test_random_caller_trees_on_many_ranks(ca, oracle, kind, nleaf, P, how, pin,
         monkeypatch.setenv("CEDR_HIP_EXCHANGE", str(mode))
         if partial:
             monkeypatch.delenv("CEDR_HIP_EXCHANGE")
-        if mode == 0:
-            mode = 2
         got = run_tree_plan(ca, nleaf, P, tree, types, v, mode, partial)
         assert np.array_equal(got, want), (mode, partial)
 

@@ -267,7 +267,8 @@ def test_qlt_random_caller_trees_ranks_as_threads(gpu, oracle, kind, nleaf, nran
                 q.declare_tracer(t, 0)
             q.end_tracer_declarations()
             q.finish_setup()
-            assert q.plan()["level_mode"] == (mode != 1)
+            if mode != 0:  # (0: the planner's choice -- level mode only if a pinned node sits inside a single-rank subtree)
+                assert q.plan()["level_mode"] == (mode == 2)
             g = q.get_owned_glblcells()
             d = [ca.DeviceArray.from_numpy(a) for a in
                  (v.rhom[g], v.Qm[:, g], v.Qm_min[:, g], v.Qm_max[:, g], v.Qm_prev[:, g])]
