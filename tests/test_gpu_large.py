@@ -201,13 +201,19 @@ def test_config_C_sharded_8_ways(gpu, oracle):
         c.finish_setup()
         return c
 
-    def run_all(nranks):
-        """(QLT, CAAS own all-reduce, CAAS + BFB reducer) results as global [nt][n] tensors."""
+    def run_all(nranks, partial=False):
+        """(QLT, CAAS own all-reduce, CAAS + BFB reducer) results as global [nt][n] tensors.
+        partial: QLT only, every rank from its own partial tree (tree::Node::level -> level mode)."""
         outs = [torch.zeros_like(Qm) for _ in range(3)]
 
         def body(rank, comm):
             par = comm.parallel(ca, rank)
-            q = declare(ca.QLT(par, n, ca.Tree.make_1d(n, nranks, False, False)))
+            tree = ca.Tree.make_1d(n, nranks, False, False)
+            if partial:
+                tree = tree.prune(rank)
+                assert tree.nnodes() < 2 * (n // nranks) + 64
+            q = declare(ca.QLT(par, n, tree))
+            assert q.plan()["level_mode"] == partial
             g = torch.from_numpy(q.get_owned_glblcells().astype(np.int64)).to(dev)
             assert int(g[0]) == rank * (n // nranks) and bool((g[1:] - g[:-1] == 1).all())  # contiguous shard
             loc = [x.index_select(x.dim() - 1, g).contiguous() for x in glob]
@@ -217,6 +223,8 @@ def test_config_C_sharded_8_ways(gpu, oracle):
             q.get_Qm(o); ca.synchronize()
             outs[0][:, g] = o
             del q
+            if partial:
+                return int(g.numel())
             c = declare(ca.CAAS(par, len(g)))
             c.set_rhom(loc[0]); c.set_Qm(loc[1], loc[2], loc[3], loc[4]); c.run()
             c.get_Qm(o); ca.synchronize()
@@ -238,6 +246,7 @@ def test_config_C_sharded_8_ways(gpu, oracle):
     q1, c1, b1 = run_all(1)
     q8, c8, b8 = run_all(P)
     assert torch.equal(q1, q8), "QLT depends on the rank count"
+    assert torch.equal(q1, run_all(P, partial=True)[0]), "QLT from partial trees (level mode) differs"
     assert torch.equal(b1, b8), "CAAS + BFB reducer depends on the rank count"
     rel = lambda a, b: float(((a - b).abs().amax(1) / b.abs().amax(1)).max())
     assert rel(c8, c1) <= 1e-13 and rel(b1, c1) <= 1e-13

@@ -45,8 +45,9 @@ def test_caas_ranks_as_threads(gpu, oracle, nranks, ncells):
     assert R.check(trs, v, got, False, verbose=False)[0] == 0
 
 
+@pytest.mark.parametrize("partial", [False, True])
 @pytest.mark.parametrize("nranks,ncells", [(4, 3000), (3, 1000), (5, 1000), (8, 1001)])
-def test_qlt_bound_arrays_ranks_as_threads(gpu, oracle, nranks, ncells):
+def test_qlt_bound_arrays_ranks_as_threads(gpu, oracle, nranks, ncells, partial):
     """Zero-copy mode across ranks: every rank binds its own slices. Ownership that cuts
     through subtrees (3, 5 ranks) includes ranks that own a lone cell as a whole subtree,
     which fall back to the packed path inside run(); the result may not depend on it."""
@@ -58,7 +59,10 @@ def test_qlt_bound_arrays_ranks_as_threads(gpu, oracle, nranks, ncells):
     out = np.zeros_like(v.Qm)
 
     def body(rank, comm):
-        q = ca.QLT(comm.parallel(ca, rank), ncells, ca.Tree.make_1d(ncells, nranks, False, False))
+        tree = ca.Tree.make_1d(ncells, nranks, False, False)
+        if partial:  # level mode: the same zero-copy rules apply to the subtrees a rank owns entirely
+            tree = tree.prune(rank)
+        q = ca.QLT(comm.parallel(ca, rank), ncells, tree)
         for t in types:
             q.declare_tracer(t, 0)
         q.end_tracer_declarations()
@@ -282,3 +286,46 @@ def test_qlt_random_caller_trees_ranks_as_threads(gpu, oracle, kind, nleaf, nran
             out[:, g] = od.numpy((len(types), len(g)))
         T.run_ranks(nranks, body)
         assert np.array_equal(out, want), (mode, partial)
+
+
+@pytest.mark.parametrize("kind,nleaf,nranks,how", [("merge", 500, 4, "scattered"), ("skew", 300, 3, "blocks"),
+                                                   ("chain", 64, 5, "scattered"), ("merge", 4000, 8, "blocks")])
+@pytest.mark.parametrize("transpose", [False, True])
+def test_bfb_random_caller_trees_ranks_as_threads(gpu, oracle, kind, nleaf, nranks, how, transpose, monkeypatch):
+    """BfbTreeAllReducer over irregular trees and scattered ownership, all three exchange forms:
+    every rank gets the bits of the single-rank sum over the same tree."""
+    import random_trees as RT
+    ca = gpu
+    nfield = 3
+    rng = np.random.default_rng(nleaf + nranks)
+    root, kid0, kid1, rank, cell = RT.random_tree(rng, nleaf, kind)
+    rank = RT.assign_ranks(rng, nleaf, rank, nranks, how)
+    glob = rng.random((nleaf, nfield)) - 0.5  # [global cell id][field]
+    lay = lambda a: np.ascontiguousarray(a.T if transpose else a).ravel()
+    r1 = np.full(len(kid0), -1, np.int32)
+    r1[:nleaf] = 0
+    leaves1 = _bfb_local_leaves(ca.Tree.from_arrays(root, kid0, kid1, r1, cell), nleaf, 0)
+    want = oracle.bfb_allreduce(oracle.Tree.from_arrays(root, kid0, kid1, r1, cell), nleaf, 1, nfield, transpose,
+                                [lay(glob[leaves1])])[0]
+    for mode, partial in ((1, False), (2, False), (2, True)):
+        monkeypatch.setenv("CEDR_HIP_EXCHANGE", str(mode))
+        if partial:
+            monkeypatch.delenv("CEDR_HIP_EXCHANGE")
+        got = [None] * nranks
+
+        def body(r, comm):
+            tree = ca.Tree.from_arrays(root, kid0, kid1, rank, cell)
+            if partial:
+                tree = tree.prune(r)
+            mine = _bfb_local_leaves(tree, nleaf, r)
+            b = ca.BfbTreeAllReducer(comm.parallel(ca, r), tree, nleaf, nfield)
+            assert b.nlocal() == len(mine)
+            sd = ca.DeviceArray.from_numpy(lay(glob[mine]))
+            rd = ca.DeviceArray(nfield)
+            for _ in range(2):
+                b.allreduce(sd, rd, transpose)
+            ca.synchronize()
+            got[r] = rd.numpy()
+        T.run_ranks(nranks, body)
+        for r in range(nranks):
+            assert np.array_equal(got[r], want), (mode, partial, r)
