@@ -467,6 +467,9 @@ __device__ __forceinline__ double micro_up_sum (const int shape, const double a,
 // (in_rows[f] + slot) instead of data + f*stride + slot -- the caller's own
 // [tracer][cell] arrays in zero-copy mode. Outputs always go to 'data'.
 // An unoptimised build keeps values in memory between statements: do not leave asm loads in flight there.
+#ifdef CEDR_DIAG_UP_BLOCKSTORE2
+__device__ double* g_diag_blk;
+#endif
 #if ! defined(__OPTIMIZE__) && ! defined(CEDR_UP_NOPREFETCH)
 # define CEDR_UP_NOPREFETCH
 #endif
@@ -613,7 +616,11 @@ void tree_up_micro_kernel (const cedr_hip_stage st, const int nfields,
     else { CEDR_WAIT_VM0_2(nab, ncc); }
 #endif
     STAMP(5);  // wait for the prefetched chunk
-#ifdef CEDR_DIAG_UP_BLOCKSTORE  // (diagnostic builds, wrong results: outputs tile-major, one contiguous block per tile)
+#ifdef CEDR_DIAG_UP_BLOCKSTORE2  // (diagnostic builds, wrong results: outputs tile-major into their own 169 MB buffer)
+    if (fl < nfields)
+      for (int k = lane >> LR; k < tile.nout; k += kWave/NR)
+        g_diag_blk[(static_cast<size_t>(tix)*nfields + fl)*16 + k] = vr[outL[k]];
+#elif defined(CEDR_DIAG_UP_BLOCKSTORE)  // (the same into a 13 MB window that wraps around: the stores stay in cache)
     if (fl < nfields)
       for (int k = lane >> LR; k < tile.nout; k += kWave/NR)
         data[static_cast<size_t>(160)*stride + static_cast<size_t>(tix)*nfields*16 % (stride - 4096) + fl*16 + k] = vr[outL[k]];
@@ -1993,6 +2000,19 @@ int cedr_hip_tree_up_rows_sums (const cedr_hip_stage* st, int32_t nfields, const
   if (lds > 160*1024) return static_cast<int>(hipErrorInvalidValue);
   const dim3 grid(st->ntiles, chunk_split(st->ntiles, (nfields + kUpFT - 1)/kUpFT, kSplitUp));
   const dim3 gridx(xcd_grid(st->ntiles), grid.y);  // micro kernels: XCD-contiguous tile ranges
+#ifdef CEDR_DIAG_UP_BLOCKSTORE2
+  {
+    static double* blk = nullptr;
+    static size_t have = 0;
+    const size_t need = static_cast<size_t>(st->ntiles)*nfields*16;
+    if (need > have) {
+      if (blk) (void) hipFree(blk);
+      if (hipMalloc(reinterpret_cast<void**>(&blk), need*sizeof(double)) != hipSuccess) return -1;
+      have = need;
+      (void) hipMemcpyToSymbol(HIP_SYMBOL(g_diag_blk), &blk, sizeof(blk));
+    }
+  }
+#endif
   if (st->micro) {
     if (st->max_nleaf > kWave) return static_cast<int>(hipErrorInvalidValue);
     auto go = [&] (auto kernel) -> int {
