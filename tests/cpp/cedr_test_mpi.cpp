@@ -10,6 +10,7 @@
 
 #include <hip/hip_runtime_api.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -45,6 +46,32 @@ static std::vector<Real> rows (const std::vector<Real>& glob, int nt, int nc, co
   return o;
 }
 
+// A rank's part of the bisection tree over cells [cs, ce), built directly as tree::Node objects the way a
+// host model does for large rank counts (cedr_tree_caller.hpp:12-30): every node gets its rank (its first
+// cell's owner) and its level; a node of another rank keeps only the kids that lead to something of this
+// rank's or that this rank's nodes need, and nkids = -1 marks "not a cell, nothing kept below".
+static cedr::tree::Node::Ptr my_tree_part (const int nc, const int nranks, const int me, const int cs, const int ce,
+                                           const cedr::tree::Node* parent) {
+  const auto owner = [&] (const int c) { return std::min(nranks - 1, c/(nc/nranks)); };  // oned::Mesh, contiguous
+  auto n = std::make_shared<cedr::tree::Node>();
+  n->parent = parent;
+  n->rank = owner(cs);
+  const int cn = ce - cs;
+  if (cn == 1) { n->nkids = 0; n->level = 0; n->cellidx = n->rank == me ? cs : -1; return n; }
+  const auto k0 = my_tree_part(nc, nranks, me, cs, cs + cn/2, n.get());
+  const auto k1 = my_tree_part(nc, nranks, me, cs + cn/2, ce, n.get());
+  n->level = 1 + std::max(k0->level, k1->level);
+  if (n->rank == me) {  // mine: both kids, whoever owns them
+    n->nkids = 2; n->kids[0] = k0; n->kids[1] = k1;
+  } else {
+    n->nkids = 0;
+    for (const auto& k : {k0, k1})
+      if (k->rank == me || k->nkids > 0) n->kids[n->nkids++] = k;
+    if (n->nkids == 0) n->nkids = -1;
+  }
+  return n;
+}
+
 int main (int argc, char** argv) {
   MPI_Init(&argc, &argv);
   int rank, size, nerr = 0;
@@ -70,9 +97,11 @@ int main (int argc, char** argv) {
       if (pts[t] & PT::nonnegative) for (int i = 0; i < nc; ++i) prev[(size_t) t*nc + i] = Qm[(size_t) t*nc + i];
     }
     // partial: the rank passes only its part of the tree (tree::Node::level) -> per-level isend/irecv
-    auto run_qlt = [&] (const cedr::mpi::Parallel::Ptr& p, std::vector<cedr::Long>& g, const bool partial = false) {
-      cedr::tree::FlatTree ft = cedr::tree::flatten(cedr::tree::make_tree_over_1d_mesh(p, nc, false));
-      if (partial) ft = cedr::tree::prune_for_rank(ft, p->rank());
+    // partial 1: prune_for_rank of the full tree; 2: tree::Node objects built part by part (my_tree_part)
+    auto run_qlt = [&] (const cedr::mpi::Parallel::Ptr& p, std::vector<cedr::Long>& g, const int partial = 0) {
+      cedr::tree::FlatTree ft = cedr::tree::flatten(partial == 2 ? my_tree_part(nc, p->size(), p->rank(), 0, nc, nullptr)
+                                                    : cedr::tree::make_tree_over_1d_mesh(p, nc, false));
+      if (partial == 1) ft = cedr::tree::prune_for_rank(ft, p->rank());
       cedr::qlt::QLT<> q(p, nc, ft);
       if (partial && p->size() > 1 && ! q.tree_engine().level_mode()) throw std::runtime_error("expected level mode");
       for (int t = 0; t < nt; ++t) q.declare_tracer(pts[t], 0);
@@ -101,13 +130,13 @@ int main (int argc, char** argv) {
     for (int t = 0; t < nt; ++t) for (size_t i = 0; i < gm.size(); ++i)
       if (std::memcmp(&mine[t*gm.size() + i], &refg[(size_t) t*nc + gm[i]], sizeof(Real))) ++nq;
     if (nq) { std::printf("rank %d FAIL QLT over MPI differs from the single-rank run in %d values\n", rank, nq); nerr += nq; }
-    {
+    for (int form = 1; form <= 2; ++form) {
       std::vector<cedr::Long> gp;
-      const std::vector<Real> part = run_qlt(pm, gp, true);
+      const std::vector<Real> part = run_qlt(pm, gp, form);
       int np = gp.size() == gm.size() ? 0 : 1;
       for (int t = 0; t < nt && ! np; ++t) for (size_t i = 0; i < gp.size(); ++i)
         if (std::memcmp(&part[t*gp.size() + i], &refg[(size_t) t*nc + gp[i]], sizeof(Real))) ++np;
-      if (np) { std::printf("rank %d FAIL QLT over partial trees differs in %d values\n", rank, np); nerr += np; }
+      if (np) { std::printf("rank %d FAIL QLT over partial trees (form %d) differs in %d values\n", rank, form, np); nerr += np; }
     }
 
     {  // CAAS, contiguous split, shape-preserving tracers only (cedr_caas.cpp:52-53)

@@ -6,6 +6,7 @@
 // would be an out-of-bounds access; here it is a message and a non-zero exit.
 #include <cstdio>
 #include <cstdlib>
+#include <memory>
 #include <set>
 #include <vector>
 
@@ -195,6 +196,65 @@ static void check_level (const tree::FlatTree& full, const int ncells, const int
   }
 }
 
+// The same partial tree two ways: pruned from the full tree, and built part by part as tree::Node objects the
+// way a host model would (tests/cpp/cedr_test_mpi.cpp has the same builder): the plans must agree.
+static tree::Node::Ptr my_tree_part (const int nc, const int nranks, const int me, const int cs, const int ce,
+                                     const tree::Node* parent) {
+  const auto owner = [&] (const int c) { return std::min(nranks - 1, c/(nc/nranks)); };
+  auto n = std::make_shared<tree::Node>();
+  n->parent = parent;
+  n->rank = owner(cs);
+  const int cn = ce - cs;
+  if (cn == 1) { n->nkids = 0; n->level = 0; n->cellidx = n->rank == me ? cs : -1; return n; }
+  const auto k0 = my_tree_part(nc, nranks, me, cs, cs + cn/2, n.get());
+  const auto k1 = my_tree_part(nc, nranks, me, cs + cn/2, ce, n.get());
+  n->level = 1 + std::max(k0->level, k1->level);
+  if (n->rank == me) { n->nkids = 2; n->kids[0] = k0; n->kids[1] = k1; }
+  else {
+    n->nkids = 0;
+    for (const auto& k : {k0, k1}) if (k->rank == me || k->nkids > 0) n->kids[n->nkids++] = k;
+    if (n->nkids == 0) n->nkids = -1;
+  }
+  return n;
+}
+
+static plan::Plan plan_of (const tree::FlatTree& t, const int nc, const int me, const int nranks) {
+  const auto ns = tree::analyze(me, nc, t);
+  util::IdMap g2l;
+  for (const Int idx : ns->levels[0].nodes) g2l.add(ns->node_h(idx)->id, ns->node_h(idx)->offset);
+  g2l.finish();
+  std::vector<int32_t> leaf_slot(t.size(), -1);
+  for (Int n = 0; n < t.size(); ++n)
+    if (t.nkids[n] == 0 && t.rank[n] == me) leaf_slot[n] = g2l.find((Int) t.cellidx[n]);
+  return plan::build(t, me, nranks, leaf_slot, plan::Options());
+}
+
+static void check_node_built_partial_trees () {
+  typedef tree::oned::Mesh Mesh;
+  const char* ctx = "node-built partial trees";
+  for (const int nc : {2, 3, 8, 17, 100, 777, 3001})
+    for (const int P : {2, 3, 4, 7}) {
+      if (P > nc) continue;
+      const tree::FlatTree full = tree::oned::make_flat_tree(Mesh(nc, P, Mesh::ParallelDecomp::contiguous), false);
+      for (int me = 0; me < P; ++me) {
+        const plan::Plan a = plan_of(tree::prune_for_rank(full, me), nc, me, P);
+        const plan::Plan b = plan_of(tree::flatten(my_tree_part(nc, P, me, 0, nc, nullptr)), nc, me, P);
+        REQUIRE(a.level_mode && b.level_mode && a.nlcl == b.nlcl && a.root_owner == b.root_owner);
+        REQUIRE(a.local.size() == b.local.size() && a.steps.size() == b.steps.size());
+        for (size_t i = 0; i < std::min(a.steps.size(), b.steps.size()); ++i) {
+          const auto& x = a.steps[i]; const auto& y = b.steps[i];
+          REQUIRE(x.level == y.level && x.nodes.size() == y.nodes.size());
+          REQUIRE(x.out_slots.size() == y.out_slots.size() && x.in_slots.size() == y.in_slots.size());
+          REQUIRE(x.out_msgs.size() == y.out_msgs.size() && x.in_msgs.size() == y.in_msgs.size());
+          for (size_t k = 0; k < std::min(x.out_msgs.size(), y.out_msgs.size()); ++k)
+            REQUIRE(x.out_msgs[k].peer == y.out_msgs[k].peer && x.out_msgs[k].count == y.out_msgs[k].count);
+          for (size_t k = 0; k < std::min(x.in_msgs.size(), y.in_msgs.size()); ++k)
+            REQUIRE(x.in_msgs[k].peer == y.in_msgs[k].peer && x.in_msgs[k].count == y.in_msgs[k].count);
+        }
+      }
+    }
+}
+
 int main () {
   typedef tree::oned::Mesh Mesh;
   char ctx[160];
@@ -228,6 +288,7 @@ int main () {
               }
         }
     }
+  check_node_built_partial_trees();
   std::printf("%ld plans checked, %d failures\n", ncase, g_fail);
   std::printf(g_fail ? "FAIL\n" : "PASS\n");
   return g_fail ? 1 : 0;
