@@ -1039,6 +1039,13 @@ void qlt_down_micro_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st
 # define CEDR_DOWN_SP_WAVES1 5  // ... and the 1-tracer-per-wave build
 #endif
 
+#ifndef CEDR_PRIO_LOADS
+# define CEDR_PRIO_LOADS 1
+#endif
+#ifndef CEDR_PRIO_LDS
+# define CEDR_PRIO_LDS 2
+#endif
+constexpr int kPrioLoads = CEDR_PRIO_LOADS, kPrioLdsLevels = CEDR_PRIO_LDS;  // (both 0: the experiment's baseline)
 template <int TW, bool ROWS>
 __global__ __launch_bounds__(kBlock, TW == 1 ? CEDR_DOWN_SP_WAVES1 : CEDR_DOWN_SP_WAVES2)
 void qlt_down_sp_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st,
@@ -1143,6 +1150,12 @@ void qlt_down_sp_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st,
   double* const R = recs + tt*pitch;          // this thread's record row in the LDS phases
 
   for (int c = blockIdx.y; c < nchunks; c += gridDim.y) {
+    // Wave priority by phase (s_setprio; 0.481 -> 0.459 ms, profiles/r02_down_experiments.md 1): a SIMD holds
+    // five waves of five workgroups in different phases. The register phase at the end of a chunk is
+    // where all four waves of a workgroup are busy and nobody waits for anybody: lowest. A chunk's
+    // loads and sums lead to the first barrier: above it. The LDS levels' node problems are done by
+    // one or two waves while the others of the workgroup wait at a barrier: highest.
+    __builtin_amdgcn_s_setprio(kPrioLoads);
     if (c != static_cast<int>(blockIdx.y)) load(c, cur, Xout, true);
 
     // ---- this wave's tracers: micro-subtree sums in registers, root records to LDS, the sums
@@ -1184,6 +1197,7 @@ void qlt_down_sp_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st,
     __syncthreads();
     // ---- node problems of the LDS levels, from the tile's outputs down, (node, tracer) items
     // spread over all threads
+    __builtin_amdgcn_s_setprio(kPrioLdsLevels);
     for (int lv = tile.nlvl - 1; lv >= 0; --lv) {
       const int a = lvlL[lv];
       const int nitems = (lvlL[lv+1] - a) << Log2<TT>::value;
@@ -1203,6 +1217,7 @@ void qlt_down_sp_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st,
       }
       __syncthreads();
     }
+    __builtin_amdgcn_s_setprio(0);
 
     // ---- this wave's tracers again: the micro-subtree's node problems in registers
 #pragma unroll
