@@ -453,6 +453,9 @@ def main():
     del out_buf
 
     ok = None
+    if a.check and a.types != "cst":
+        raise SystemExit("--check verifies bounds and mass conservation, the properties of cst tracers; "
+                         "mixed types are checked against the oracle in tests/")
     if a.check:
         out = torch.empty_like(Qm)
         qlt.get_Qm(out)

@@ -728,6 +728,13 @@ void micro_solves (const int shape, const bool any2, const bool any3, const int 
 }
 
 
+#ifndef CEDR_PRIO_LOADS
+# define CEDR_PRIO_LOADS 1
+#endif
+#ifndef CEDR_PRIO_LDS
+# define CEDR_PRIO_LDS 2
+#endif
+constexpr int kPrioLoads = CEDR_PRIO_LOADS, kPrioLdsLevels = CEDR_PRIO_LDS;  // (both 0: the experiment's baseline)
 // Root -> leaves over micro tiles. 4 tracers per chunk, one per wave for the
 // register part; the LDS part spreads (node, tracer) items over all threads.
 #ifndef CEDR_MICRO_WAVES
@@ -877,6 +884,8 @@ void qlt_down_micro_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st
       for (int s = 0; s < TW; ++s) load(c*TT + wave + kNW*s, cur[s], true);
     }
 
+    // (wave priorities by phase as in qlt_down_sp_kernel: sums and level sums 1, LDS node problems 2, register phase 0)
+    __builtin_amdgcn_s_setprio(kPrioLoads);
     // ---- this wave's tracers: micro-subtree sums in registers, root records to LDS
 #pragma unroll
     for (int s = 0; s < TW; ++s) {
@@ -937,6 +946,7 @@ void qlt_down_micro_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st
     }
     __syncthreads();
     STAMP(3);  // phase A + outputs' masses
+    __builtin_amdgcn_s_setprio(kPrioLdsLevels);
     for (int lv = tile.nlvl - 1; lv >= 0; --lv) {
       const int a = lvlL[lv];
       const int nitems = (lvlL[lv+1] - a) << Log2<TT>::value;
@@ -961,6 +971,7 @@ void qlt_down_micro_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st
       __syncthreads();
     }
 
+    __builtin_amdgcn_s_setprio(0);
     STAMP(4);  // phase B
     // ---- this wave's tracers again: node problems of the micro-subtree in
     // registers, then the cells' masses to HBM.
@@ -1039,13 +1050,6 @@ void qlt_down_micro_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st
 # define CEDR_DOWN_SP_WAVES1 5  // ... and the 1-tracer-per-wave build
 #endif
 
-#ifndef CEDR_PRIO_LOADS
-# define CEDR_PRIO_LOADS 1
-#endif
-#ifndef CEDR_PRIO_LDS
-# define CEDR_PRIO_LDS 2
-#endif
-constexpr int kPrioLoads = CEDR_PRIO_LOADS, kPrioLdsLevels = CEDR_PRIO_LDS;  // (both 0: the experiment's baseline)
 template <int TW, bool ROWS>
 __global__ __launch_bounds__(kBlock, TW == 1 ? CEDR_DOWN_SP_WAVES1 : CEDR_DOWN_SP_WAVES2)
 void qlt_down_sp_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st,
