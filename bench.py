@@ -68,6 +68,9 @@ def parse():
     ap.add_argument("--same-gpu", action="store_true",
                     help="rehearsal: every rank uses GPU 0 (needs --comm gloo)")
     return ap.parse_args()
+    if a.check and a.types != "cst":
+        ap.error("--check verifies bounds and mass conservation, the properties of cst tracers; mixed types are "
+                 "checked against the oracle in tests/")
 
 
 def gen_inputs(torch, n, nt, seed, device):
@@ -453,9 +456,6 @@ def main():
     del out_buf
 
     ok = None
-    if a.check and a.types != "cst":
-        raise SystemExit("--check verifies bounds and mass conservation, the properties of cst tracers; "
-                         "mixed types are checked against the oracle in tests/")
     if a.check:
         out = torch.empty_like(Qm)
         qlt.get_Qm(out)
