@@ -67,10 +67,11 @@ def parse():
                          "cst, st, ct, t, nn, cnn in turn (diagnostic)")
     ap.add_argument("--same-gpu", action="store_true",
                     help="rehearsal: every rank uses GPU 0 (needs --comm gloo)")
-    return ap.parse_args()
+    a = ap.parse_args()
     if a.check and a.types != "cst":
         ap.error("--check verifies bounds and mass conservation, the properties of cst tracers; mixed types are "
                  "checked against the oracle in tests/")
+    return a
 
 
 def gen_inputs(torch, n, nt, seed, device):
