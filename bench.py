@@ -494,7 +494,7 @@ def main():
 
     if rank == 0:
         line = {
-            "metric": "cell-tracer-updates/sec (QLT+CAAS), 1.5M cells x 40 tracers; % HBM roofline",
+            "metric": "cell-tracer-updates/sec (QLT+CAAS), 1.5M cells \u00d7 40 tracers; % HBM roofline",  # BASELINE.json's string
             "value": value, "unit": "cell-tracer-updates/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
