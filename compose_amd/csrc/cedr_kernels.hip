@@ -1977,7 +1977,10 @@ inline int pitch_for (int n) { return (n + 30)/32*32 + 1; }
 // workgroup per CU slot is enough); the root->leaves kernels are limited by the
 // last, partly idle round of workgroups and prefer ~4 rounds (measured at 187 500
 // cells x 40 tracers, the 8-GPU shard: 0.117 -> 0.103 ms).
-constexpr int kSplitUp = 1024, kSplitDown = 3072;  // kSplitDown: micro tiles only
+// (Round 2, five workgroups per CU: 2048 instead of 3072 -- a 1024-tile stage of 10 chunks then runs 2 workgroups of
+// 5 chunks per tile instead of 4 + 4 + 2: 0.0549 -> 0.0534 ms at 1.5M cells' second stage, 0.0706 -> 0.0695 ms at the
+// shard's first; 5120 and 10240 are slower.)
+constexpr int kSplitUp = 1024, kSplitDown = 2048;  // kSplitDown: micro tiles only
 // (Round 2: splitting the first stage's tiles too -- 9000 or 17000 workgroups wanted -- does not shorten
 // the last, partly idle round: 0.488 -> 0.492 / 0.514 ms.)
 inline int chunk_split (int ntiles, int nchunks, int target) {
