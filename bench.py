@@ -102,7 +102,7 @@ def gen_inputs(torch, n, nt, seed, device):
 
 
 def cpu_baseline(ncells, nt):
-    """The oracle (CPU port of the reference algorithm, built -O3 -ffp-contract=off) timed on this
+    """The oracle (CPU port of the reference algorithm, built by oracle/Makefile; the flags are read back from the library) timed on this
     host on the metric's own configuration: the reported CPU baseline, never the thing measured as
     `value`. One thread (the reference's Kokkos-Serial shape) and the box's CPU share (OpenMP over
     level nodes / tracers, as cedr_qlt.cpp:391-393,570-572 and cedr_caas.cpp:187)."""
@@ -150,7 +150,7 @@ def cpu_baseline(ncells, nt):
         if nthr == 1:
             res["all"] = res["1"]
             break
-    return res, nthr
+    return res, nthr, o.lib().or_build_flags().decode()
 
 
 def spawn_ranks(a):
@@ -404,22 +404,30 @@ def main():
             gbs = alg[(name, aux)] / (avg_ms * 1e-3) / 1e9
             e.update(algorithmic_bytes=alg[(name, aux)], achieved_GBs=gbs, frac=gbs / HBM_PEAK_GBS)
         kernels.append(e)
-    # HBM traffic per launch from the PMC counters of a profiling run of this same
-    # command (profiles/r02_traffic.json, made by tools/profile_traffic.sh).
-    try:
-        tr = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
-        if world == 1 and tr["config"] == {"ncells": ncells, "ntracers": nt}:
+    # HBM traffic per launch: NOT measured by this run. It is read from the committed PMC profile of
+    # this same command (profiles/rNN_traffic.json, made by tools/profile_traffic.sh; the newest
+    # round's file whose configuration matches), and the line says so in roofline.traffic_source.
+    traffic_source = None
+    for cand in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles"))
+                        if f.startswith("r") and f.endswith("_traffic.json")), reverse=True):
+        try:
+            tr = json.load(open(os.path.join(ROOT, "profiles", cand)))
+            if world != 1 or tr["config"] != {"ncells": ncells, "ntracers": nt}:
+                continue
             for k in kernels:
                 t = tr["kernels"].get(k["kernel"])
                 if t and "algorithmic_bytes" in k:
                     k["traffic"] = t["hbm_bytes"]
-    except (OSError, ValueError, KeyError):
-        pass
+            traffic_source = "profiles/" + cand + " (PMC run of this command, not this run)"
+            break
+        except (OSError, ValueError, KeyError):
+            continue
     dom = next((k for k in kernels if "achieved_GBs" in k), None)
     roofline = None
     if dom:
         roofline = dict(bound="hbm", kernel=dom["kernel"], achieved=dom["achieved_GBs"],
                         peak=HBM_PEAK_GBS, unit="GB/s", frac=dom["frac"], traffic=dom.get("traffic"),
+                        traffic_source=traffic_source if dom.get("traffic") is not None else None,
                         avg_ms=dom["avg_ms"], algorithmic_bytes_per_launch=dom["algorithmic_bytes"],
                         launch="first stage: %d workgroups (tiles)" % dom["launch"],
                         rocprof="every stage runs the same sweep kernels (qlt_down_sp_kernel / tree_up_micro_kernel),"
@@ -477,14 +485,14 @@ def main():
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         try:
             cc = a.cpu_cells or ncells
-            res, nthr = cpu_baseline(cc, nt)
+            res, nthr, oflags = cpu_baseline(cc, nt)
             cpu = dict(value=res["all"]["value"], unit="cell-tracer-updates/s", cores=res["all"]["threads"],
                        kind="port",
-                       sample="oracle (CPU port of the reference algorithm, g++ -O3 -ffp-contract=off, OpenMP "
-                              "over level nodes / tracers) QLT::run + CAAS::run on %d cells x %d cst tracers%s: "
+                       sample="oracle (CPU port of the reference algorithm, built with '%s' as the library itself "
+                              "reports, OpenMP over level nodes / tracers) QLT::run + CAAS::run on %d cells x %d cst tracers%s: "
                               "%d + %d runs on %d threads (this box's CPU share for one GPU; the host reports "
                               "%d CPUs), and %d + %d runs on 1 thread (single_thread)"
-                              % (cc, nt, "" if cc == ncells else " (a sample of the %d-cell configuration)" % ncells,
+                              % (oflags, cc, nt, "" if cc == ncells else " (a sample of the %d-cell configuration)" % ncells,
                                  res["all"]["qlt_runs"], res["all"]["caas_runs"], nthr, os.cpu_count() or 0,
                                  res["1"]["qlt_runs"], res["1"]["caas_runs"]),
                        host_cores=os.cpu_count(), single_thread=res["1"], all_threads=res["all"])

@@ -69,7 +69,7 @@ public:
     bool need_conserve_;
     Real* d_;
   };
-  const DeviceOp& get_device_op();
+  const DeviceOp& get_device_op() override;
 
   void run() override;
 

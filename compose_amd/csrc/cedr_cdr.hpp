@@ -56,6 +56,12 @@ struct CDR {
   //   get_Qm(lclcellidx, tracer_idx)
   struct DeviceOp {};
 
+  // reference cedr_cdr.hpp:104. Through a CDR::Ptr this returns the tag base; callers
+  // static_cast it to the concrete CDR's DeviceOp before copying it into a kernel, as the
+  // reference's callers do (cedr_test_randomized_inl.hpp:27-28). QLT and CAAS override it
+  // with a covariant return type, so `qlt.get_device_op()` yields the concrete POD directly.
+  virtual const DeviceOp& get_device_op() = 0;
+
   // Enqueue the algorithm on the CDR's HIP stream over the values set through
   // the DeviceOp; results are read through the DeviceOp afterwards, stream
   // ordered. Not to be called from a parallel region.

@@ -91,7 +91,7 @@ public:
     const Int* trcr2bl2r;
     const Int* trcr2br2l;
   };
-  const DeviceOp& get_device_op();
+  const DeviceOp& get_device_op() override;
 
   void run() override;
 

@@ -23,6 +23,12 @@ extern "C" {
 
 const char* or_last_error() { return g_err.c_str(); }
 
+// Compiler and flags this library was built with (oracle/Makefile passes them in).
+#ifndef OR_BUILD_FLAGS
+# define OR_BUILD_FLAGS "unknown"
+#endif
+const char* or_build_flags() { return OR_BUILD_FLAGS; }
+
 int or_max_threads() {
 #ifdef _OPENMP
   return omp_get_max_threads();

@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <type_traits>
 #include <vector>
 
 #include "cedr_caas.hpp"
@@ -201,7 +202,12 @@ static int drive (const char* name, CDRT& cdr, const std::vector<Tracer>& ts, in
   HIP_OK(hipMemcpy(d[0], v.rhom.data(), n*sizeof(Real), hipMemcpyHostToDevice));
   const Real* src[] = {v.Qm.data(), v.lo.data(), v.hi.data(), v.prev.data()};
   for (int k = 0; k < 4; ++k) HIP_OK(hipMemcpy(d[k+1], src[k], N, hipMemcpyHostToDevice));
-  const auto op = cdr.get_device_op();  // by value into the kernels below
+  // As the reference's callers do (cedr_test_randomized_inl.hpp:27-28): hold the CDR through its base,
+  // ask THAT for the DeviceOp (the virtual of cedr_cdr.hpp:104) and cast to the concrete type; by value
+  // into the kernels below.
+  cedr::CDR& base = cdr;
+  const auto op = static_cast<const typename CDRT::DeviceOp&>(base.get_device_op());
+  static_assert(std::is_trivially_copyable<typename CDRT::DeviceOp>::value, "DeviceOp is copied into kernels");
   const int B = 256;
   k_set_rhom<<<(n + B - 1)/B, B>>>(op, n, d[0]);
   for (int trial = 0; trial < 2; ++trial) {  // the second run repeats the first

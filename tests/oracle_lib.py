@@ -43,6 +43,7 @@ def lib():
         build()
     L = C.CDLL(path)
     L.or_last_error.restype = C.c_char_p
+    L.or_build_flags.restype = C.c_char_p
     for name in ("or_tree_make_1d", "or_tree_from_arrays", "or_analyze", "or_qlt_create",
                  "or_caas_create", "or_qlt_nodesets"):
         getattr(L, name).restype = C.c_void_p
