@@ -11,7 +11,8 @@ spawned before anything touches a GPU; rank 0's JSON line is relayed), and
 `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` works too.
 The global problem is sharded contiguously over ranks (strong scaling). The data
 path uses the library's own RCCL communicator (one all-gather per QLT run, one
-all-reduce per CAAS run, strictly ordered on ONE stream when N > 1);
+all-reduce per CAAS run; at N > 1 the two CDRs run on two streams by default and the
+library orders the communicator's collectives across them with events, --serial = one stream);
 torch.distributed (gloo) is only the control plane (unique-id broadcast, barriers,
 max over ranks). A transport that fails ends the run with a non-zero exit code.
 """
@@ -50,8 +51,10 @@ def parse():
                          "shard of an 8-GPU run); 'down' = CAAS::run begins when QLT::run reaches its first-stage "
                          "root->leaves sweep (fp64-issue bound, so the memory-bound CAAS kernels fit beside it). With N > 1 "
                          "the two CDRs still share ONE communicator, whose collectives the library orders "
-                         "with events across streams; the default for N > 1 stays one stream.")
-    ap.add_argument("--serial", action="store_true", help="(default now; kept for older command lines)")
+                         "with events across streams. Default: one stream at N = 1, 'start' at N > 1 (the "
+                         "latency of each CDR's one small collective then hides behind the other CDR's kernels).")
+    ap.add_argument("--serial", action="store_true",
+                    help="QLT::run then CAAS::run back to back on one stream, also at N > 1")
     ap.add_argument("--comm", choices=["rccl", "gloo"], default="rccl",
                     help="data-path transport for N > 1: the library's RCCL communicator (default) or, "
                          "for rehearsals on one GPU, host-staged torch.distributed/gloo callbacks")
@@ -198,6 +201,8 @@ def spawn_ranks(a):
 
 def main():
     a = parse()
+    if a.gpus > 1 and a.overlap is None and not a.serial:
+        a.overlap = "start"
     if a.gpus > 1 and "RANK" not in os.environ:
         spawn_ranks(a)  # does not return
     import torch

@@ -122,6 +122,7 @@ _SIGS = {
     "cedr_plan_summary": (C.c_int, [_vp, C.POINTER(C.c_int64)]),
     "cedr_plan_stage_sizes": (C.c_int, [_vp, C.c_int, C.c_int, _ip]),
     "cedr_plan_stage": (C.c_int, [_vp, C.c_int, C.c_int, _ip, C.POINTER(C.c_uint16), _ip]),
+    "cedr_plan_stage_is_top": (C.c_int, [_vp, C.c_int, C.c_int]),
     "cedr_plan_stage_micro": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(C.c_uint16), C.POINTER(C.c_uint16)]),
     "cedr_plan_exchange": (C.c_int, [_vp, _ip, _ip, _ip]),
     "cedr_plan_levels": (C.c_int, [_vp, _ip]),
@@ -548,7 +549,8 @@ def dump_plan(h, nranks=1):
             _chk(L.cedr_plan_stage_micro(h, top, i, micro.ctypes.data_as(C.POINTER(C.c_uint16)),
                                          outs.ctypes.data_as(C.POINTER(C.c_uint16))))
             out[key].append(dict(tiles=tiles, kids=kids, lvlptr=lvlptr, max_nodes=sz[1],
-                                 micro=micro[:sz[4]], outs=outs[:sz[5]]))
+                                 micro=micro[:sz[4]], outs=outs[:sz[5]],
+                                 top=bool(L.cedr_plan_stage_is_top(h, top, i))))
     out["my_root_slots"], out["my_top_slots"], out["gather_slots"] = plan_exchange(h, nranks)
     info = (C.c_int * 3)()
     L.cedr_plan_levels(h, info)

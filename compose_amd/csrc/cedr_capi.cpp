@@ -291,6 +291,9 @@ void* cedr_plan_create (void* tree, int ncells, int my_rank, int nranks, int max
   if (const char* e = std::getenv("CEDR_HIP_MICRO_CUT2")) o.micro_cut2 = std::atoi(e);
   if (const char* e = std::getenv("CEDR_HIP_MICRO")) o.micro_all = std::atoi(e) >= 2;
   if (const char* e = std::getenv("CEDR_HIP_EXCHANGE")) o.exchange = std::atoi(e);
+  // fused top tile (plan::Stage::top): 0 = off (every stage its own launch, as before round 3)
+  if (const char* e = std::getenv("CEDR_HIP_TOP")) o.fused_top = std::atoi(e) != 0;
+  if (const char* e = std::getenv("CEDR_HIP_TOP_MAX")) o.top_max_inputs = std::atoi(e);
   PlanBox* b = new PlanBox();
   b->owned = plan::build(t, my_rank, nranks, leaf_slot, o);
   b->p = &b->owned;
@@ -328,6 +331,11 @@ int cedr_plan_stage_sizes (void* h, int top, int idx, int* sz) {
   sz[4] = static_cast<int>(st->micro.size());
   sz[5] = static_cast<int>(st->outs.size());
   return 0;
+}
+int cedr_plan_stage_is_top (void* h, int top, int idx) {
+  const plan::Stage* st = get_stage(h, top, idx);
+  if ( ! st) { g_err = "no such stage"; return -1; }
+  return st->top ? 1 : 0;
 }
 int cedr_plan_stage_micro (void* h, int top, int idx, uint16_t* micro, uint16_t* outs) {
   const plan::Stage* st = get_stage(h, top, idx);

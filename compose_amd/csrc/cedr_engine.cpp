@@ -21,6 +21,7 @@ void DeviceStage::upload (const plan::Stage& st) {
                           s.nout, s.outs_off};
   }
   tiles.upload(tl);
+  tile0 = tl.empty() ? cedr_hip_tile{0, 0, 0, 0, 0, 0, 0, 0, 0, 0} : tl[0];
   kids.upload(st.kids);
   lvlptr.upload(st.lvlptr);
   h.ntiles = static_cast<int32_t>(st.tiles.size());
@@ -54,7 +55,23 @@ TreeEngine::TreeEngine (const mpi::Parallel::Ptr& p, const tree::FlatTree& t,
       cedr_throw_if(lci < 0, "owned leaf " << t.cellidx[n] << " missing from NodeSets");
       leaf_slot[n] = lci;
     }
-  plan_ = plan::build(t, me, p->size(), leaf_slot, opt);
+  // A transport without point-to-point messages (Comm::has_exchange) cannot run a level-mode plan.
+  // Full trees: plan for the all-gather instead, which works for any ownership (every rank sees the
+  // same communicator type, so all decide alike). Partial trees need the messages: refuse here, in
+  // the constructor and on every rank, not at the first level step inside run().
+  plan::Options popt = opt;
+  if (p->size() > 1 && ! p->comm()->has_exchange()) {
+    bool partial = false;
+    for (Int n = 0; n < t.size(); ++n)
+      if (t.level[n] >= 0 || (t.nkids[n] != 2 && t.nkids[n] != 0)) partial = true;
+    cedr_throw_if(partial || popt.exchange == 2,
+                  "this tree is partial (tree::Node::level is set), or per-level exchange was requested, "
+                  "which needs one round of point-to-point messages per tree level, but the communicator has "
+                  "no point-to-point exchange (mpi::Comm::has_exchange): pass make_parallel_callbacks its "
+                  "third callback, use RCCL, or the MPI adapter");
+    popt.exchange = 1;
+  }
+  plan_ = plan::build(t, me, p->size(), leaf_slot, popt);
   // Rounded up to 16 doubles (128-byte rows) with at least two spare slots per
   // row: the kernels' 16-byte cell loads may read up to two slots past a tile.
   stride_ = (static_cast<int64_t>(plan_.nslots) + 2 + 15)/16*16;
@@ -119,32 +136,57 @@ bool TreeEngine::first_stage_takes_rows () const {
   return true;
 }
 
-void TreeEngine::up (int32_t nfields, const uint8_t* op_dev, double* data, bool zero_init,
-                     hipStream_t stream, const double* const* in_rows) {
+// The local stages, leaves->root. pack_roots: the fused top tile's launch also packs this rank's
+// boundary roots' records into sendbuf_ (the gather launch fused in).
+void TreeEngine::up_local (int32_t nfields, const uint8_t* op_dev, double* data, bool zero_init,
+                           hipStream_t stream, const double* const* in_rows, bool skip_top, bool pack_roots) {
   cedr_throw_if( ! uploaded_, "TreeEngine::upload was not called");
-  for (size_t i = 0; i < local_.size(); ++i)
-    cedr_k_check(cedr_hip_tree_up_rows_sums(&local_[i]->h, nfields, op_dev, stride_, data,
-                                            i == 0 ? in_rows : nullptr, plan_.nlcl, zero_init, all_sums_, stream));
+  for (size_t i = 0; i < local_.size(); ++i) {
+    if (plan_.local[i].top) {
+      if (skip_top) continue;
+      cedr_k_check(cedr_hip_tree_top_up(&local_[i]->h, &local_[i]->tile0, nfields, op_dev, stride_, data, zero_init,
+                                        pack_roots ? static_cast<int32_t>(plan_.my_root_slots.size()) : 0,
+                                        pack_roots ? my_root_slots_.data() : nullptr,
+                                        pack_roots ? sendbuf_.data() : nullptr, stream));
+    } else {
+      cedr_k_check(cedr_hip_tree_up_rows_sums(&local_[i]->h, nfields, op_dev, stride_, data,
+                                              i == 0 ? in_rows : nullptr, plan_.nlcl, zero_init, all_sums_, stream));
+    }
+  }
+}
+
+void TreeEngine::up (int32_t nfields, const uint8_t* op_dev, double* data, bool zero_init,
+                     hipStream_t stream, const double* const* in_rows, bool skip_top) {
+  const bool xch = ! plan_.level_mode && ! top_.empty();
+  if (xch) size_exchange_buffers(nfields);
+  up_local(nfields, op_dev, data, zero_init, stream, in_rows, skip_top, xch && has_top());
   if (plan_.level_mode) { up_levels(nfields, op_dev, data, zero_init, stream); return; }
   if (top_.empty()) return;
-  exchange(nfields, data, stream);
+  exchange(nfields, data, stream, has_top());
   cedr_k_check(cedr_hip_scatter_slots(data, stride_, nfields, gather_slots_.data(),
                                       plan_.nranks*plan_.nb_max, recvbuf_.data(), stream));
   for (const auto& st : top_)
     cedr_k_check(cedr_hip_tree_up(&st->h, nfields, op_dev, stride_, data, zero_init, stream));
 }
 
-// Gather this rank's boundary roots and all-gather them: recvbuf_ = [rank][nb_max][nfields].
-void TreeEngine::exchange (int32_t nfields, double* data, hipStream_t stream) {
+void TreeEngine::size_exchange_buffers (int32_t nfields) {
   const int32_t P = plan_.nranks, nb = plan_.nb_max;
   if (nfields > xfields_) {
     sendbuf_.alloc_zero(static_cast<size_t>(nb)*nfields);
     recvbuf_.alloc_zero(static_cast<size_t>(P)*nb*nfields);
     xfields_ = nfields;
   }
-  cedr_k_check(cedr_hip_gather_slots(data, stride_, nfields, my_root_slots_.data(),
-                                     static_cast<int32_t>(plan_.my_root_slots.size()),
-                                     sendbuf_.data(), stream));
+}
+
+// Gather this rank's boundary roots (unless the top tile's launch already packed them) and
+// all-gather them: recvbuf_ = [rank][nb_max][nfields].
+void TreeEngine::exchange (int32_t nfields, double* data, hipStream_t stream, bool gathered) {
+  const int32_t nb = plan_.nb_max;
+  size_exchange_buffers(nfields);
+  if ( ! gathered)
+    cedr_k_check(cedr_hip_gather_slots(data, stride_, nfields, my_root_slots_.data(),
+                                       static_cast<int32_t>(plan_.my_root_slots.size()),
+                                       sendbuf_.data(), stream));
   const int err = p_->comm()->allgather(sendbuf_.data(), recvbuf_.data(),
                                         static_cast<size_t>(nb)*nfields, stream);
   cedr_throw_if(err != 0, "allgather of subtree roots returned " << err);
@@ -154,10 +196,9 @@ const double* TreeEngine::up_to_exchange (int32_t nfields, const uint8_t* op_dev
                                           bool zero_init, hipStream_t stream,
                                           const double* const* in_rows) {
   cedr_throw_if( ! uploaded_ || ! apex_, "up_to_exchange needs an uploaded plan with an apex tile");
-  for (size_t i = 0; i < local_.size(); ++i)
-    cedr_k_check(cedr_hip_tree_up_rows_sums(&local_[i]->h, nfields, op_dev, stride_, data,
-                                            i == 0 ? in_rows : nullptr, plan_.nlcl, zero_init, all_sums_, stream));
-  exchange(nfields, data, stream);
+  size_exchange_buffers(nfields);
+  up_local(nfields, op_dev, data, zero_init, stream, in_rows, false, has_top());
+  exchange(nfields, data, stream, has_top());
   return recvbuf_.data();
 }
 

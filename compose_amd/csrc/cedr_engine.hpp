@@ -19,6 +19,7 @@ struct DeviceStage {
   dev::Buffer<uint16_t> kids, micro, outs;
   dev::Buffer<int32_t> lvlptr;
   cedr_hip_stage h;
+  cedr_hip_tile tile0;  // host copy of the first tile's descriptor (the single-tile stages: top, apex)
   void upload(const plan::Stage& st);
 };
 
@@ -43,8 +44,16 @@ public:
   // global root's record on every rank.
   // in_rows (optional, device table of nfields row pointers): the first local stage reads
   // its inputs from in_rows[f][slot] instead of data (zero-copy mode).
+  // skip_top: leave out the fused top tile (has_top()); the caller sweeps it itself (QLT on one
+  // rank: cedr_hip_qlt_top mode 1 re-forms the tile's sums and computes the root in its one launch).
   void up(int32_t nfields, const uint8_t* op_dev, double* data, bool zero_init,
-          hipStream_t stream, const double* const* in_rows = nullptr);
+          hipStream_t stream, const double* const* in_rows = nullptr, bool skip_top = false);
+  // The fused top tile (plan::Stage::top): the last local stage, swept by the tracer-parallel top
+  // kernels in one launch per direction.
+  bool has_top () const { return ! plan_.local.empty() && plan_.local.back().top; }
+  const cedr_hip_stage* top_stage () const { return &local_.back()->h; }
+  const cedr_hip_tile* top_tile () const { return &local_.back()->tile0; }  // host copy of its descriptor
+  const cedr_hip_tile* apex_tile () const { return &apex_->tile0; }
   // The owner's promise that every field's combine rule is a plain sum (op_dev all zero).
   void set_all_sums (bool v) { all_sums_ = v; }
   // Multi-rank runs whose replicated top fits one apex tile (plan::Plan::apex): the leaves->root
@@ -88,7 +97,10 @@ private:
   std::vector<std::unique_ptr<DeviceStage> > local_, top_;
   std::unique_ptr<DeviceStage> apex_;
   dev::Buffer<int32_t> my_root_slots_, my_top_slots_, gather_slots_, apex_src_, apex_my_in_;
-  void exchange(int32_t nfields, double* data, hipStream_t stream);
+  void exchange(int32_t nfields, double* data, hipStream_t stream, bool gathered = false);
+  void size_exchange_buffers(int32_t nfields);
+  void up_local(int32_t nfields, const uint8_t* op_dev, double* data, bool zero_init, hipStream_t stream,
+                const double* const* in_rows, bool skip_top, bool pack_roots);
   struct StepOff { size_t nodes, outs, ins; };
   std::vector<StepOff> lvl_off_;
   dev::Buffer<int32_t> lvl_nodes_, lvl_outs_, lvl_ins_;

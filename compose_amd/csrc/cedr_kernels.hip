@@ -1476,6 +1476,453 @@ void tree_apex_sum_kernel (const cedr_hip_stage st, const double* __restrict__ r
   }
 }
 
+// -------------------------------------------------------------- fused top
+// The last, latency-bound stages of a rank's forest as ONE plain tile (plan::Stage::top: up to 2048
+// inputs = the outputs of the last micro stage, all tree levels above them, one output per subtree
+// root of the rank). Tracers (fields) are independent, so the tile is swept tracer-parallel: one
+// workgroup of 512 threads per tracer -- or per group of FPB fields on the way up -- walks ALL levels
+// in one launch with workgroup barriers between them; no grid barrier, no launch per stage. The
+// inputs stay in HBM / L2 (only the lowest internal level reads them, coalesced); the internal
+// nodes live in LDS. A kid with local id < nleaf is an input, else internal node id - nleaf.
+// Replaces, per direction, the launches of stages 3-4 (cedr_qlt.cpp:339-430, 525-604 for those
+// levels) and -- fused in -- gather_slots (:432-439), root_compute (:441-476) or the apex launch.
+constexpr int kTopBlock = 1024;
+
+#ifdef CEDR_TOP_STAMPS
+// Diagnostic build only: wall-clock stamps (10 ns units) of workgroup 0's thread 0 at the phase
+// boundaries of qlt_top_kernel (slots 0..31) and tree_top_up_kernel (32..63).
+__device__ unsigned long long g_top_stamps[64];
+# define TSTAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_top_stamps[i] = wall_clock64(); } while (0)
+#else
+# define TSTAMP(i)
+#endif
+
+struct TopMeta {
+  uint32_t* kidsL;
+  int32_t* lvlL;
+  double* rest;  // first double after the metadata
+};
+// The tile descriptor comes by value (the host knows it), so the first thing the kernel waits for is
+// already the kid table itself.
+__device__ __forceinline__ TopMeta top_stage_meta (const cedr_hip_stage& st, const cedr_hip_tile& tile,
+                                                   double* lds) {
+  TopMeta m;
+  m.kidsL = reinterpret_cast<uint32_t*>(lds);
+  m.lvlL = reinterpret_cast<int32_t*>(m.kidsL + st.max_nint);
+  m.rest = lds + (2*static_cast<size_t>(st.max_nint) + 2 + 1)/2;
+  const uint32_t* __restrict__ kp = reinterpret_cast<const uint32_t*>(st.kids + 2*static_cast<size_t>(tile.kids_off));
+  for (int j = threadIdx.x; j < tile.nint; j += kTopBlock) m.kidsL[j] = kp[j];
+  const int32_t* __restrict__ lp = st.lvlptr + tile.lvl_off;
+  for (int j = threadIdx.x; j <= tile.nlvl; j += kTopBlock) m.lvlL[j] = lp[j];
+  return m;
+}
+
+// Leaves->root, any combine rules. grid.x = ceil(nfields/FPB); lane -> (node, field) with the field
+// fastest. Outputs go to their slots (data[f*stride + tile.out + k]); with sendbuf != NULL the
+// records of this rank's nroots boundary roots are packed as [root][field] for the exchange as well
+// (a root that is not an output of this tile was finished by an earlier stage: read from its slot).
+// The lowest level (both kids of every node are inputs) takes its <= 1024 x FPB items in one pass of
+// eight per thread, so that all of the kernel's HBM / L2 reads are in flight together.
+template <int FPB>
+__global__ __launch_bounds__(kTopBlock)
+void tree_top_up_kernel (const cedr_hip_stage st, const cedr_hip_tile tile, const int nfields,
+                         const uint8_t* __restrict__ op, const int64_t stride, double* __restrict__ data,
+                         const int zero_init, const int nroots, const int32_t* __restrict__ root_slots,
+                         double* __restrict__ sendbuf) {
+  extern __shared__ double lds[];
+  const int nleaf = tile.nleaf;
+  const int pitch = st.max_nint | 1;
+  constexpr int LF = Log2<FPB>::value;
+  const int ff = threadIdx.x & (FPB - 1);
+  const int f = blockIdx.x*FPB + ff;
+  const bool live = f < nfields;
+  const double* __restrict__ const row = data + static_cast<size_t>(live ? f : 0)*stride + tile.in0;
+  // level 0 straight from the kid table in global memory: its input loads can go out before the
+  // table has been staged in LDS
+  const uint32_t* __restrict__ const kp = reinterpret_cast<const uint32_t*>(st.kids + 2*static_cast<size_t>(tile.kids_off));
+  // (n0 is only needed once the loads are under way: nodes past level 0 among the first 1024 just
+  // load an input for nothing)
+  const int n0 = tile.nlvl > 0 ? st.lvlptr[tile.lvl_off + 1] : 0;
+  constexpr int NB0 = 1024*FPB/kTopBlock;  // items of level 0 per thread
+  double k0[NB0], k1[NB0];
+  {
+    uint32_t kk[NB0];
+#pragma unroll
+    for (int u = 0; u < NB0; ++u) {
+      const int q = threadIdx.x + u*kTopBlock;
+      kk[u] = (q >> LF) < tile.nint ? kp[q >> LF] : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < NB0; ++u) {
+      const int c0 = kk[u] & 0xffff, c1 = kk[u] >> 16;
+      k0[u] = row[c0 < nleaf ? c0 : 0];
+      k1[u] = row[c1 < nleaf ? c1 : 0];
+    }
+  }
+  const TopMeta M = top_stage_meta(st, tile, lds);
+  double* const v = M.rest;  // [FPB][pitch]
+  const int o = live ? op[f] : 0;
+  double* const vf = v + ff*pitch;
+  auto val = [&] (const int c) -> double { return c < nleaf ? row[c] : vf[c - nleaf]; };
+  TSTAMP(32);
+#pragma unroll
+  for (int u = 0; u < NB0; ++u) {
+    const int q = threadIdx.x + u*kTopBlock;
+    if ((q >> LF) < n0 && live) vf[q >> LF] = combine(o, zero_init, k0[u], k1[u]);
+  }
+  __syncthreads();
+  TSTAMP(33);
+  for (int lv = 1; lv < tile.nlvl; ++lv) {
+    const int a = M.lvlL[lv];
+    const int nitems = (M.lvlL[lv+1] - a) << LF;
+    for (int q0 = threadIdx.x; q0 < nitems; q0 += 2*kTopBlock) {
+      double c0[2], c1[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int q = q0 + u*kTopBlock;
+        c0[u] = c1[u] = 0;
+        if (q < nitems && live) {
+          const uint32_t kk = M.kidsL[a + (q >> LF)];
+          c0[u] = val(kk & 0xffff);
+          c1[u] = val(kk >> 16);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int q = q0 + u*kTopBlock;
+        if (q < nitems && live) vf[a + (q >> LF)] = combine(o, zero_init, c0[u], c1[u]);
+      }
+    }
+    __syncthreads();
+  }
+  TSTAMP(34);
+  if ( ! live) return;
+  for (int k = threadIdx.x >> LF; k < tile.nout; k += kTopBlock/FPB)
+    data[static_cast<size_t>(f)*stride + tile.out + k] = val(st.outs[tile.outs_off + k]);
+  if (sendbuf)
+    for (int j = threadIdx.x >> LF; j < nroots; j += kTopBlock/FPB) {
+      const int s = root_slots[j], k = s - tile.out;
+      sendbuf[static_cast<size_t>(j)*nfields + f] =
+        (k >= 0 && k < tile.nout) ? val(st.outs[tile.outs_off + k]) : data[static_cast<size_t>(f)*stride + s];
+    }
+}
+
+// QLT over the top tile, one workgroup per tracer (bulk index blockIdx.x): re-forms the sums of the
+// tile's internal nodes from its inputs, obtains the assigned masses of the tile's outputs, and sweeps
+// the node problems (cedr_qlt.cpp:525-604, cedr_qlt_inl.hpp:120-203) down to the inputs' r2l slots.
+// mode 0: the outputs' masses (and a consistent-only tracer's global q bounds) are in their r2l slots
+//         (staged replicated top, level mode).
+// mode 1: single rank: the tile's one output is the global root; root_compute (cedr_qlt.cpp:441-476)
+//         happens here, on sums that then include Qm_prev -- no leaves->root launch over the top tile
+//         is needed at all.
+// mode 2: multi-rank with an apex tile: what qlt_apex_kernel does for this tracer (gathered boundary
+//         records -> up, root_compute, down) gives this rank's boundary roots their masses first.
+// LDS record per internal node and tracer: {lo / q_min, orig, hi / q_max, Qm_prev sum going up ->
+// assigned mass X going down}, plus rhom, 1/rhom, 1/(1/rhom) per node.
+// 1024 threads: a level has at most nleaf/2 <= 1024 nodes, one per thread. The lowest level -- both kids
+// of each node are inputs -- keeps its kids' records in REGISTERS from the sums to the node problems: the
+// tile's inputs are read from HBM / L2 once, all loads in flight together at the start, and nothing at
+// the end of the dependent chain of levels waits for memory. The root->leaves part is ONE loop over the
+// apex tile's levels (mode 2) and then the top tile's, with a single inlined copy of the node problem:
+// the kernel runs once per step on a cold instruction cache, so its code size is launch latency.
+struct TopApex {
+  cedr_hip_stage st;
+  cedr_hip_tile tile;
+  const double* recv;
+  const int32_t* src;
+  int32_t nmine;
+  const int32_t* my_in;
+  const int32_t* my_slot;
+};
+
+__global__ __launch_bounds__(kTopBlock)
+void qlt_top_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st, const cedr_hip_tile tile,
+                     double* __restrict__ l2r, double* __restrict__ r2l, const int mode, const TopApex A) {
+  extern __shared__ double lds[];
+  const int nleaf = tile.nleaf, nint = tile.nint, MI = st.max_nint;
+  const size_t S = static_cast<size_t>(L.stride);
+  const bool prefer = L.prefer_mass_con != 0;
+  const int bi = blockIdx.x;
+  const int pt = L.bidx_prob[bi], lb = L.bidx_l2r[bi], rb = L.bidx_r2l[bi];
+  const bool sp = (pt & SHAPEPRESERVE) != 0;
+  const bool t_only = (pt & CONSISTENT) && ! sp;
+  const bool cons = (pt & CONSERVE) != 0;
+  const int in0 = tile.in0;
+  const int tid = threadIdx.x;
+  // l2r field of record entry k (-1: the tracer has none), as in qlt_apex_kernel
+  auto field_of = [&] (const int k) -> int {
+    if (pt & NONNEGATIVE) return k == 1 ? lb : ((k == 3 && cons) ? lb + 1 : -1);
+    return (k < 3 || cons) ? lb + k : -1;
+  };
+  auto rule_of = [&] (const int k) -> int { return (t_only && k == 0) ? 1 : ((t_only && k == 2) ? 2 : 0); };
+  const double* __restrict__ const rrow = l2r + in0;
+  TSTAMP(0);
+
+  // ---- level 0 in registers: kid indices straight from global memory, then every load at once.
+  // (n0 is only needed once the loads are under way: a node past level 0 just loads an input for nothing)
+  const uint32_t* __restrict__ const kp = reinterpret_cast<const uint32_t*>(st.kids + 2*static_cast<size_t>(tile.kids_off));
+  const int n0 = tile.nlvl > 0 ? st.lvlptr[tile.lvl_off + 1] : 0;
+  int c0r[2];               // this thread's level-0 node: its kids' input indices
+  double f0[2][4], r0[2];   // their records and densities
+  {
+    const uint32_t kk = tid < nint ? kp[tid] : 0;
+    const int a = kk & 0xffff, b = kk >> 16;
+    c0r[0] = a < nleaf ? a : 0; c0r[1] = b < nleaf ? b : 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int fk = field_of(k);
+      const bool want = fk >= 0 && (k < 3 || mode == 1);
+      const double* __restrict__ const frow = l2r + static_cast<size_t>(fk < 0 ? 0 : fk)*S + in0;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) f0[e][k] = want ? frow[c0r[e]] : 0.0;
+    }
+#pragma unroll
+    for (int e = 0; e < 2; ++e) r0[e] = rrow[c0r[e]];
+  }
+  // Mode 2: everything the apex part will need from global memory is requested now as well -- the
+  // gathered records (through src), this thread's boundary root and where it goes -- so that it arrives
+  // while the tile's sums are formed. One item per thread: an apex tile has <= 64 inputs.
+  const int an = A.tile.nleaf, nf = L.l2rndps;
+  double av = 0, avr = 0;
+  int my_in_r = 0, my_slot_r = -1, my_node_r = -1;
+  const int root_node = mode == 1 ? st.outs[tile.outs_off] : 0;
+  if (mode == 2) {
+    if (tid < 4*an) {
+      const int fk = field_of(tid & 3);
+      const size_t rec = static_cast<size_t>(A.src[tid >> 2])*nf;
+      av = fk >= 0 ? A.recv[rec + fk] : 0.0;
+      if ((tid & 3) == 0) avr = A.recv[rec];
+    }
+    if (tid < A.nmine) {
+      my_in_r = A.my_in[tid];
+      my_slot_r = A.my_slot[tid];
+      const int k = my_slot_r - tile.out;
+      my_node_r = (k >= 0 && k < tile.nout) ? st.outs[tile.outs_off + k] : -1;
+    }
+  }
+  const TopMeta M = top_stage_meta(st, tile, lds);
+  double* const rho = M.rest;
+  double* const rw = rho + MI;
+  double* const rq = rw + MI;
+  double* const recs = rq + MI;          // [nint][4]
+  double* const apx = recs + 4*static_cast<size_t>(MI);
+  // apex part of the LDS (mode 2): every node of the apex tile, inputs first
+  const int AM = A.st.max_nodes;
+  uint32_t* const akids = reinterpret_cast<uint32_t*>(apx);
+  int32_t* const alvl = reinterpret_cast<int32_t*>(akids + A.st.max_nint);
+  double* const arho = apx + (2*static_cast<size_t>(A.st.max_nint) + 2 + 1)/2;
+  double* const arw = arho + AM;
+  double* const arq = arw + AM;
+  double* const arec = arq + AM;         // [an + ai][4]
+  int aroot = 0;
+  if (mode == 2) {
+    const uint32_t* __restrict__ akp = reinterpret_cast<const uint32_t*>(A.st.kids + 2*static_cast<size_t>(A.tile.kids_off));
+    for (int j = tid; j < A.tile.nint; j += kTopBlock) akids[j] = akp[j];
+    const int32_t* __restrict__ lp = A.st.lvlptr + A.tile.lvl_off;
+    for (int j = tid; j <= A.tile.nlvl; j += kTopBlock) alvl[j] = lp[j];
+    aroot = A.st.outs[A.tile.outs_off];
+  }
+  if (tid < n0) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) recs[4*tid + k] = combine(rule_of(k), 0, f0[0][k], f0[1][k]);
+    rho[tid] = r0[0] + r0[1];
+  }
+  __syncthreads();
+  TSTAMP(1);
+
+  // ---- sums of the other internal nodes, level by level: entries 0..2 (and 3 = Qm_prev when the
+  // root is computed here) of every node's record, and its density. A kid may still be an input.
+  {
+    const int k = tid & 3;
+    const int fk = field_of(k);
+    const bool want = fk >= 0 && (k < 3 || mode == 1);
+    const double* __restrict__ const frow = l2r + static_cast<size_t>(fk < 0 ? 0 : fk)*S + in0;
+    const int ok = rule_of(k);
+    for (int lv = 1; lv < tile.nlvl; ++lv) {
+      const int a = M.lvlL[lv], n = M.lvlL[lv+1] - a;
+      for (int q = tid; q < 4*n; q += kTopBlock) {
+        double r = 0.0;
+        if (want) {
+          const uint32_t kk = M.kidsL[a + (q >> 2)];
+          const int c0 = kk & 0xffff, c1 = kk >> 16;
+          r = combine(ok, 0, c0 < nleaf ? frow[c0] : recs[4*(c0 - nleaf) + k],
+                      c1 < nleaf ? frow[c1] : recs[4*(c1 - nleaf) + k]);
+        }
+        recs[4*(a + (q >> 2)) + k] = r;
+      }
+      if (tid < n) {
+        const uint32_t kk = M.kidsL[a + tid];
+        const int c0 = kk & 0xffff, c1 = kk >> 16;
+        rho[a + tid] = (c0 < nleaf ? rrow[c0] : rho[c0 - nleaf]) + (c1 < nleaf ? rrow[c1] : rho[c1 - nleaf]);
+      }
+      __syncthreads();
+    }
+    for (int j = tid; j < nint; j += kTopBlock) {
+      const double w = 1.0/rho[j];
+      rw[j] = w;
+      rq[j] = 1.0/w;
+    }
+  }
+
+  TSTAMP(2);
+  // ---- assigned masses of the tile's outputs; the global q bounds of a consistent-only tracer
+  double qlo = 0, qhi = 0;
+  // an output that is an input of the tile (a subtree root the previous stage finished): pass on
+  auto put_input = [&] (const int c, const double x, const double ql, const double qh) {
+    r2l[rb*S + in0 + c] = x;
+    if (t_only) {  // the q bounds travel with the mass (cedr_qlt.cpp:549-560)
+      r2l[(rb + 1)*S + in0 + c] = ql; r2l[(rb + 2)*S + in0 + c] = qh;
+      l2r[lb*S + in0 + c] = ql; l2r[(lb + 2)*S + in0 + c] = qh;
+    }
+  };
+  if (mode == 0) {
+    if (t_only) { qlo = r2l[(rb + 1)*S + tile.out]; qhi = r2l[(rb + 2)*S + tile.out]; }
+    for (int k = tid; k < tile.nout; k += kTopBlock) {
+      const int node = st.outs[tile.outs_off + k];
+      const double x = r2l[rb*S + tile.out + k];
+      if (node >= nleaf) recs[4*(node - nleaf) + 3] = x;
+      else put_input(node, x, qlo, qhi);
+    }
+  } else if (mode == 1) {
+    // root_compute: the root's mass is its Qm_prev sum (conserving tracers) or its Qm sum; the
+    // record's entry 3 already holds the former
+    const int node = root_node;
+    if (node >= nleaf) {
+      const double* const R = recs + 4*(node - nleaf);
+      if (t_only) { qlo = R[0]; qhi = R[2]; }
+      if (tid == 0 && ! cons) recs[4*(node - nleaf) + 3] = R[1];
+    } else {  // a one-cell tree: the root is the input itself
+      const int fo = field_of(cons ? 3 : 1);
+      if (t_only) { qlo = l2r[lb*S + in0 + node]; qhi = l2r[(lb + 2)*S + in0 + node]; }
+      if (tid == 0) put_input(node, l2r[fo*S + in0 + node], qlo, qhi);
+    }
+  } else {
+    // apex, leaves->root: this tracer's records of all ranks' boundary roots, then root_compute
+    const cedr_hip_tile at = A.tile;
+    if (tid < 4*an) {
+      arec[tid] = av;
+      if ((tid & 3) == 0) arho[tid >> 2] = avr;
+    }
+    __syncthreads();
+    for (int lv = 0; lv < at.nlvl; ++lv) {
+      const int a = alvl[lv], n = alvl[lv+1] - a;
+      for (int q = tid; q < 5*n; q += kTopBlock) {
+        const uint32_t kk = akids[a + q/5];
+        const int k = q % 5, c0 = kk & 0xffff, c1 = kk >> 16, me = an + a + q/5;
+        if (k == 4) arho[me] = arho[c0] + arho[c1];
+        else arec[4*me + k] = combine(rule_of(k), 0, arec[4*c0 + k], arec[4*c1 + k]);
+      }
+      __syncthreads();
+    }
+    for (int i = tid; i < an + at.nint; i += kTopBlock) {
+      const double w = 1.0/arho[i];
+      arw[i] = w;
+      arq[i] = 1.0/w;
+    }
+    if (t_only) { qlo = arec[4*aroot]; qhi = arec[4*aroot + 2]; }
+    __syncthreads();
+    if (tid == 0 && ! cons) arec[4*aroot + 3] = arec[4*aroot + 1];
+  }
+
+  // ---- node problems: the apex tile's levels from its root down (mode 2), the hand-over of this
+  // rank's boundary roots, then the top tile's levels from its outputs down. One node per thread and
+  // level. What a node problem needs of an INPUT kid of the top tile comes from global memory (level 0:
+  // from the registers) and does not depend on the level above: it is requested before the barrier that
+  // publishes that level's results, so its latency overlaps the wait.
+  const int fo = sp ? lb + 1 : ((pt & CONSISTENT) ? lb + 1 : lb);  // the 'orig' field
+  const double* __restrict__ const orow = l2r + static_cast<size_t>(fo)*S + in0;
+  const double* __restrict__ const lrow = l2r + static_cast<size_t>(lb)*S + in0;        // lo (sp)
+  const double* __restrict__ const hrow = l2r + static_cast<size_t>(lb + 2)*S + in0;    // hi (sp)
+  const int asteps = mode == 2 ? A.tile.nlvl : 0;
+  TSTAMP(3);
+  for (int s = 0; s < asteps + tile.nlvl; ++s) {
+    if (s < 24) TSTAMP(4 + s);
+    const bool ap = s < asteps;
+    const int lv = ap ? asteps - 1 - s : tile.nlvl - 1 - (s - asteps);
+    const uint32_t* const KD = ap ? akids : M.kidsL;
+    const int32_t* const LV = ap ? alvl : M.lvlL;
+    const int a = LV[lv], n = LV[lv+1] - a;
+    const int thr = ap ? 0 : nleaf;      // kid ids below thr are inputs in global memory
+    const int off = ap ? 0 : nleaf;      // LDS index of kid c: c - off
+    const int pb = ap ? an : 0;          // LDS index of this level's node j: pb + j
+    double* const RC = ap ? arec : recs;
+    const double* const RH = ap ? arho : rho;
+    const double* const RW = ap ? arw : rw;
+    const double* const RQ = ap ? arq : rq;
+    const bool regs = ! ap && lv == 0;   // the top tile's lowest level: kids in this thread's registers
+    if (mode == 2 && s == asteps) {
+      // this rank's boundary roots: to their r2l slots (roots an earlier stage finished are read from
+      // there by that stage) and, for this tile's outputs, into the tile
+      __syncthreads();
+      if (tid < A.nmine) {
+        const double x = arec[4*my_in_r + 3];
+        r2l[rb*S + my_slot_r] = x;
+        if (t_only) { r2l[(rb + 1)*S + my_slot_r] = qlo; r2l[(rb + 2)*S + my_slot_r] = qhi; }
+        if (my_node_r >= nleaf) recs[4*(my_node_r - nleaf) + 3] = x;
+        else if (my_node_r >= 0) put_input(my_node_r, x, qlo, qhi);
+      }
+    }
+    const bool act = tid < n;
+    int cc[2] = {off, off};
+    double krh[2] = {1, 1}, klo[2] = {0, 0}, kor[2] = {0, 0}, khi[2] = {0, 0};
+    if (regs) {
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        cc[e] = c0r[e]; krh[e] = r0[e]; klo[e] = f0[e][0]; kor[e] = f0[e][1]; khi[e] = f0[e][2];
+      }
+    } else if (act) {
+      const uint32_t kk = KD[a + tid];
+      cc[0] = kk & 0xffff; cc[1] = kk >> 16;
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+        if (cc[e] < thr) {
+          krh[e] = rrow[cc[e]];
+          kor[e] = orow[cc[e]];
+          if (sp) { klo[e] = lrow[cc[e]]; khi[e] = hrow[cc[e]]; }
+        }
+    }
+    // Everything but the node's own assigned mass is independent of the level above -- the kids' sums
+    // and densities in LDS as well: read before the barrier, so that only one LDS read and the node
+    // problem itself follow it.
+    KidRho kr[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      if (regs || cc[e] < thr) {
+        const double w = 1.0/krh[e];
+        kr[e] = KidRho{krh[e], w, 1.0/w};
+      } else if (act) {
+        const int ci = cc[e] - off;
+        kr[e] = KidRho{RH[ci], RW[ci], RQ[ci]};
+        klo[e] = RC[4*ci]; kor[e] = RC[4*ci + 1]; khi[e] = RC[4*ci + 2];
+      }
+    }
+    const int me = pb + a + (act ? tid : 0);
+    const double* const P = RC + 4*me;
+    const double plo = P[0], por = P[1], phi = P[2], prh = RH[me];
+    __syncthreads();
+    if ( ! act) continue;
+    double xs[2];
+    solve_node(pt, prh, t_only ? qlo : plo, por, t_only ? qhi : phi, P[3],
+               kr[0], t_only ? qlo : klo[0], kor[0], t_only ? qhi : khi[0],
+               kr[1], t_only ? qlo : klo[1], kor[1], t_only ? qhi : khi[1], xs[0], xs[1], prefer);
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      if (regs || cc[e] < thr) put_input(cc[e], xs[e], qlo, qhi);
+      else RC[4*(cc[e] - off) + 3] = xs[e];
+    }
+  }
+  TSTAMP(30);
+  if (mode == 2 && tile.nlvl == 0) {  // (a top tile of copies only: the hand-over still has to happen)
+    __syncthreads();
+    if (tid < A.nmine) {
+      const double x = arec[4*my_in_r + 3];
+      r2l[rb*S + my_slot_r] = x;
+      if (t_only) { r2l[(rb + 1)*S + my_slot_r] = qlo; r2l[(rb + 2)*S + my_slot_r] = qhi; }
+      if (my_node_r >= 0) put_input(my_node_r, x, qlo, qhi);
+    }
+  }
+}
+
 // ----------------------------------------------------------- slot shuffles
 __global__ void gather_slots_kernel (const double* __restrict__ data, const int64_t stride,
                                      const int nfields, const int32_t* __restrict__ slots,
@@ -1916,12 +2363,13 @@ __global__ void node_problem_batch_kernel (const int pt, const int nprob, const 
 // is launched on. Off by default; bench.py switches it on for its roofline leg.
 enum KernelId : int { K_TREE_UP = 0, K_QLT_DOWN, K_QLT_ROOT, K_GATHER, K_SCATTER, K_COPY,
                       K_SET_RHOM, K_SET_QM, K_GET_QM, K_CAAS_REDUCE, K_CAAS_SUM, K_CAAS_ACCUM,
-                      K_CAAS_FINISH, K_APEX, K_LEVEL, K_COUNT };
+                      K_CAAS_FINISH, K_APEX, K_LEVEL, K_TOP_UP, K_QLT_TOP, K_COUNT };
 const char* const kKernelNames[K_COUNT] = {
   "tree_up_kernel", "qlt_down_kernel", "qlt_root_kernel", "gather_slots_kernel",
   "scatter_slots_kernel", "copy_slots_kernel", "qlt_set_rhom_kernel", "qlt_set_Qm_kernel",
   "qlt_get_Qm_kernel", "caas_reduce_kernel", "caas_sum_partials_kernel",
-  "caas_reduce_accum_kernel", "caas_finish_kernel", "apex_kernel", "level_kernel" };
+  "caas_reduce_accum_kernel", "caas_finish_kernel", "apex_kernel", "level_kernel", "tree_top_up_kernel",
+  "qlt_top_kernel" };
 
 struct ProfRec { int id; int64_t aux; hipEvent_t a, b; };
 struct Profiler {
@@ -2159,6 +2607,56 @@ int cedr_hip_qlt_apex (const cedr_hip_qlt_layout* lay, const cedr_hip_stage* st,
   if (e) return e;
   hipLaunchKernelGGL(qlt_apex_kernel, dim3(1), dim3(kBlock), lds, stream, *lay, *st, recv, src, nmine, my_in,
                      my_slot, r2l, tt, pitch);
+  return launch_status();
+}
+
+constexpr int kTopFPB = 4;  // fields per workgroup, leaves->root over the top tile
+
+// tile: HOST copy of the stage's one tile descriptor (the kernels take it by value)
+static bool top_stage_ok (const cedr_hip_stage* st, const cedr_hip_tile* t) {
+  return st->ntiles == 1 && ! st->micro && st->max_nleaf <= 2048 && st->max_nodes <= 4095 && t &&
+    t->nleaf >= 1 && t->nleaf <= st->max_nleaf && t->nint >= 0 && t->nint <= st->max_nint && t->nlvl >= 0 &&
+    t->nlvl <= t->nint && t->nout >= 1;
+}
+
+int cedr_hip_tree_top_up (const cedr_hip_stage* st, const cedr_hip_tile* tile, int32_t nfields, const uint8_t* op,
+                          int64_t stride, double* data, int zero_init, int32_t nroots, const int32_t* root_slots,
+                          double* sendbuf, cedr_stream_t stream) {
+  ProfScope ps(K_TOP_UP, st->max_nleaf, stream);
+  if (nfields == 0) return 0;
+  if ( ! top_stage_ok(st, tile) || (sendbuf && ! root_slots)) return static_cast<int>(hipErrorInvalidValue);
+  const size_t lds = sizeof(double)*(static_cast<size_t>(st->max_nint) + 1 +
+                                     static_cast<size_t>(kTopFPB)*(st->max_nint | 1));
+  int e = set_lds_limit(tree_top_up_kernel<kTopFPB>, lds);
+  if (e) return e;
+  hipLaunchKernelGGL(tree_top_up_kernel<kTopFPB>, dim3((nfields + kTopFPB - 1)/kTopFPB), dim3(kTopBlock), lds,
+                     stream, *st, *tile, nfields, op, stride, data, zero_init, nroots, root_slots, sendbuf);
+  return launch_status();
+}
+
+int cedr_hip_qlt_top (const cedr_hip_qlt_layout* lay, const cedr_hip_stage* st, const cedr_hip_tile* tile,
+                      double* l2r, double* r2l, int mode, const cedr_hip_stage* apex,
+                      const cedr_hip_tile* apex_tile, const double* recv, const int32_t* src,
+                      int32_t nmine, const int32_t* my_in, const int32_t* my_slot, cedr_stream_t stream) {
+  ProfScope ps(K_QLT_TOP, st->max_nleaf, stream);
+  if (lay->nt == 0) return 0;
+  if ( ! top_stage_ok(st, tile) || mode < 0 || mode > 2 || (mode == 1 && tile->nout != 1))
+    return static_cast<int>(hipErrorInvalidValue);
+  size_t lds = sizeof(double)*(8*static_cast<size_t>(st->max_nint) + 1);
+  TopApex A;
+  A.st = *st; A.tile = *tile; A.recv = nullptr; A.src = nullptr; A.nmine = 0; A.my_in = nullptr; A.my_slot = nullptr;
+  if (mode == 2) {
+    if ( ! apex || ! apex_tile || apex->ntiles != 1 || apex->micro || apex->max_nleaf > 64 || ! recv || ! src ||
+        apex_tile->nleaf > apex->max_nleaf || apex_tile->nint > apex->max_nint || nmine > apex_tile->nleaf ||
+        (nmine > 0 && ( ! my_in || ! my_slot)))
+      return static_cast<int>(hipErrorInvalidValue);
+    A.st = *apex; A.tile = *apex_tile; A.recv = recv; A.src = src; A.nmine = nmine; A.my_in = my_in; A.my_slot = my_slot;
+    lds += sizeof(double)*(static_cast<size_t>(apex->max_nint) + 1 + 7*static_cast<size_t>(apex->max_nodes));
+  }
+  if (lds > 160*1024) return static_cast<int>(hipErrorInvalidValue);
+  int e = set_lds_limit(qlt_top_kernel, lds);
+  if (e) return e;
+  hipLaunchKernelGGL(qlt_top_kernel, dim3(lay->nt), dim3(kTopBlock), lds, stream, *lay, *st, *tile, l2r, r2l, mode, A);
   return launch_status();
 }
 
@@ -2402,6 +2900,12 @@ int cedr_hip_profile_get (int i, int* id, int64_t* aux, float* ms) {
   *aux = r.aux;
   return static_cast<int>(hipEventElapsedTime(ms, r.a, r.b));
 }
+
+#ifdef CEDR_TOP_STAMPS
+int cedr_hip_debug_top_stamps (unsigned long long* out) {
+  return static_cast<int>(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_top_stamps), sizeof(unsigned long long)*64));
+}
+#endif
 
 #ifdef CEDR_STAMPS
 int cedr_hip_debug_stamps (unsigned long long* out, int reset) {

@@ -26,6 +26,7 @@ struct SelfComm : public Comm {
   int allreduce_sum (const Real* send, Real* recv, size_t count, hipStream_t s) override {
     return allgather(send, recv, count, s);
   }
+  bool has_exchange () const override { return true; }  // no peers: there is never a message
 };
 
 // ------------------------------------------------------------------------ RCCL
@@ -121,6 +122,7 @@ struct RcclComm : public Comm {
     order_after(s);
     return e;
   }
+  bool has_exchange () const override { return rccl().p2p; }
   int exchange (const P2P* ops, int nops, hipStream_t s) override {
     if (nops == 0) return 0;
     const RcclApi& a = rccl();
@@ -153,6 +155,7 @@ struct CallbackComm : public Comm {
   int allreduce_sum (const Real* send, Real* recv, size_t count, hipStream_t s) override {
     return ar_(user_, send, recv, count, s);
   }
+  bool has_exchange () const override { return xch_ != nullptr; }
   int exchange (const P2P* ops, int nops, hipStream_t s) override {
     if (nops == 0) return 0;
     if ( ! xch_) return -2;

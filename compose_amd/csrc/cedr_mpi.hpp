@@ -40,6 +40,10 @@ struct Comm {
   // the default (an error if such a plan is run).
   struct P2P { int peer; Real* buf; size_t count; int send; };
   virtual int exchange (const P2P* /*ops*/, int nops, hipStream_t /*stream*/) { return nops == 0 ? 0 : -2; }
+  // Whether exchange() is implemented. A transport without it runs every full tree through the
+  // all-gather (TreeEngine plans accordingly) and rejects partial trees when the CDR is constructed
+  // -- on every rank alike -- instead of failing inside run().
+  virtual bool has_exchange () const { return false; }
 };
 
 // What Parallel::comm() returns: the Comm of this build, usable as the shared_ptr it is -- and,

@@ -74,6 +74,7 @@ struct MpiComm : public Comm {
   }
   // One tree level's messages of a level-mode plan (partial trees): the reference's isend / irecv /
   // waitall, cedr_qlt.cpp:327-337,432-439, with its tag.
+  bool has_exchange () const override { return true; }
   int exchange (const P2P* ops, int nops, hipStream_t s) override {
     if (nops == 0) return 0;
     enum { tag = 42 };

@@ -72,7 +72,10 @@ struct Builder {
 
   // Append the tile rooted at tree node r to st. Inputs are the nodes with
   // slot >= 0 met by the DFS, in DFS order; their slots must be consecutive.
-  void build_tile (Stage& st, const int32_t r) {
+  void build_tile (Stage& st, const int32_t r) { build_tile(st, std::vector<int32_t>(1, r)); }
+
+  // Several roots (DFS order): the fused top tile over a forest. Its outputs are the roots.
+  void build_tile (Stage& st, const std::vector<int32_t>& rts) {
     Tile tile;
     tile.micro_off = micro_mode ? static_cast<int32_t>(st.micro.size()) : 0;
     int32_t nreal = 0;  // real leaves seen so far (micro mode)
@@ -83,7 +86,7 @@ struct Builder {
     int32_t nleaf = 0, in0 = -1;
     {
       std::vector<std::pair<int32_t,int32_t> > stack;
-      stack.push_back(std::make_pair(r, 0));
+      for (auto it = rts.rbegin(); it != rts.rend(); ++it) stack.push_back(std::make_pair(*it, 0));
       while ( ! stack.empty()) {
         auto& top = stack.back();
         const int32_t n = top.first;
@@ -144,6 +147,7 @@ struct Builder {
     tile.nleaf = nleaf;
     tile.nint = static_cast<int32_t>(internals.size());
     cedr_throw_if(tile.nleaf + tile.nint > 65535, "tile too large for 16-bit local ids");
+    cedr_throw_if(rts.size() > 1 && cut > 0, "a tile over several roots cannot be cut");
     // Kids before parents: order internal nodes by local level, DFS order within.
     std::stable_sort(internals.begin(), internals.end(),
                      [&] (int32_t a, int32_t b) { return llvl[a] < llvl[b]; });
@@ -167,7 +171,7 @@ struct Builder {
     // where its first input sits.
     std::vector<int32_t> outs;
     if (dropped.empty()) {
-      outs.push_back(r);
+      outs = rts;
     } else {
       for (const int32_t n : inputs) has_parent[n] = 0;
       for (const int32_t n : internals) has_parent[n] = 0;
@@ -198,16 +202,39 @@ struct Builder {
   // Reduce every root in 'roots' to a single input slot, appending stages.
   // micro: 0 = no stage uses micro tiles, 1 = the first stage does, 2 = all do.
   void tile_forest (const std::vector<int32_t>& roots, std::vector<Stage>& stages,
-                    const int micro, const bool cut_first) {
+                    const int micro, const bool cut_first, const bool fuse_top = false) {
     bool first = true;
+    std::vector<int32_t> prev_active;  // the roots the previous stage still worked on
     for (int istage = 0;; ++istage) {
       micro_mode = micro == 2 || (micro == 1 && first);
-      stage_cut = ! cut_first ? 0 : (istage == 0 ? opt.micro_cut : (istage == 1 ? opt.micro_cut2 : 0));
+      // With a fused top every stage from the second on is cut like the second: the levels a cut
+      // leaves out land in the top tile's launch. Without, only the first two may be cut: later
+      // stages are small, and a cut there would add a stage = a launch in each direction.
+      stage_cut = ! cut_first ? 0 : (istage == 0 ? opt.micro_cut :
+                                     ((istage == 1 || fuse_top) ? opt.micro_cut2 : 0));
       first = false;
       std::vector<int32_t> active;
       for (const int32_t r : roots) if (slot[r] < 0) active.push_back(r);
       if (active.empty()) break;
-      if (micro_mode) for (const int32_t r : active) count_slots(r);
+      for (const int32_t r : active) count_slots(r);
+      if (fuse_top && istage > 0) {
+        // What is left above the previous stage's outputs, which are consecutive slots: the roots
+        // that stage finished (one slot each; copies in the top tile) and everything below the
+        // roots still open. Few enough: ONE plain tile over all of them ends the forest.
+        int64_t left = 0;
+        for (const int32_t r : prev_active) left += slot[r] >= 0 ? 1 : nin[r];
+        if (left <= opt.top_max_inputs) {
+          micro_mode = false;
+          stage_cut = 0;
+          Stage st;
+          st.top = true;
+          pending.clear();
+          build_tile(st, prev_active);
+          for (const auto& p : pending) slot[p.first] = p.second;
+          stages.push_back(std::move(st));
+          break;
+        }
+      }
       for (const int32_t r : active) count_inputs(r);
       Stage st;
       pending.clear();
@@ -226,6 +253,7 @@ struct Builder {
       }
       for (const auto& p : pending) slot[p.first] = p.second;
       stages.push_back(std::move(st));
+      prev_active.swap(active);
     }
     micro_mode = false;
   }
@@ -280,7 +308,7 @@ static Plan build_level_mode (const tree::FlatTree& t, const int32_t me, const i
   std::vector<int32_t> my_roots;
   for (int32_t n = 0; n < nn; ++n)
     if (pure[n] && (t.parent[n] < 0 || ! pure[t.parent[n]])) my_roots.push_back(n);
-  b.tile_forest(my_roots, p.local, opt.micro ? (opt.micro_all ? 2 : 1) : 0, true);
+  b.tile_forest(my_roots, p.local, opt.micro ? (opt.micro_all ? 2 : 1) : 0, true, opt.fused_top);
   for (const int32_t r : my_roots) p.my_root_slots.push_back(b.slot[r]);
 
   // Slots of the rest of my nodes and of their kids elsewhere.
@@ -358,6 +386,8 @@ Plan build (const tree::FlatTree& t, int32_t my_rank, int32_t nranks,
   const int32_t nn = t.size();
   cedr_throw_if(opt.max_tile_leaves < 2 || opt.max_tile_leaves > 256,
                 "max_tile_leaves must be in [2, 256]");
+  cedr_throw_if(opt.fused_top && (opt.top_max_inputs < 2 || opt.top_max_inputs > 2048),
+                "top_max_inputs must be in [2, 2048]");
   Plan p;
   p.my_rank = my_rank;
   p.nranks = nranks;
@@ -431,7 +461,7 @@ Plan build (const tree::FlatTree& t, int32_t my_rank, int32_t nranks,
 
   std::vector<int32_t> my_roots;
   for (const int32_t r : broots) if (own[r] == my_rank) my_roots.push_back(r);
-  b.tile_forest(my_roots, p.local, opt.micro ? (opt.micro_all ? 2 : 1) : 0, true);
+  b.tile_forest(my_roots, p.local, opt.micro ? (opt.micro_all ? 2 : 1) : 0, true, opt.fused_top);
   for (const int32_t r : my_roots) p.my_root_slots.push_back(b.slot[r]);
 
   if (broots.size() > 1) {

@@ -65,6 +65,14 @@ struct Stage {
   // the outputs as consecutive input slots. Cutting shortens the chain of
   // dependent tree levels a workgroup has to walk per tile.
   std::vector<uint16_t> outs;
+  // FUSED TOP (plan::Options::fused_top): the stage is ONE plain tile over everything that is left
+  // of this rank's forest above the previous stage's outputs -- up to Options::top_max_inputs
+  // inputs, several tree levels, one output per subtree root of the rank (an input that is itself
+  // such a root is an output too: a copy). It is swept by the tracer-parallel top kernels
+  // (cedr_hip_tree_top_up / cedr_hip_qlt_top): one workgroup per tracer (or group of fields) walks
+  // ALL its levels in one launch, instead of one launch per stage for the last, latency-bound
+  // stages. Always the last local stage.
+  bool top = false;
 };
 
 // LEVEL MODE. When the caller hands every rank only its part of the tree (tree::Node::level,
@@ -130,6 +138,12 @@ struct Options {
   // 2 = level mode. Every rank must use the same value; the automatic rule only looks at numbers
   // every rank computes alike.
   int32_t exchange = 0;
+  // The last local stages as one fused top tile (Stage::top) once at most top_max_inputs slots
+  // are left below this rank's unfinished roots; every micro stage before it is then cut
+  // (micro_cut2 from the second on): the levels a cut leaves out end up in the top tile's single
+  // launch, not in an extra stage.
+  bool fused_top = true;
+  int32_t top_max_inputs = 2048;  // bounded by the top kernels' LDS use (4095 nodes of 56 B)
 };
 
 // 'leaf_slot[n]' gives, for every tree node n that is a leaf owned by my_rank,

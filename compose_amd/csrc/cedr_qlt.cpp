@@ -126,6 +126,9 @@ void QLTHip::init (const Parallel::Ptr& p, const Int& ncells, const tree::FlatTr
   if (const char* e = std::getenv("CEDR_HIP_MICRO_CUT2")) popt.micro_cut2 = std::atoi(e);
   // 1 = all-gather + replicated top, 2 = per-level point-to-point; default: decided from the tree
   if (const char* e = std::getenv("CEDR_HIP_EXCHANGE")) popt.exchange = std::atoi(e);
+  // fused top tile (plan::Stage::top): 0 = off (every stage its own launch, as before round 3)
+  if (const char* e = std::getenv("CEDR_HIP_TOP")) popt.fused_top = std::atoi(e) != 0;
+  if (const char* e = std::getenv("CEDR_HIP_TOP_MAX")) popt.top_max_inputs = std::atoi(e);
   eng_.reset(new engine::TreeEngine(p, tree, *ns_, popt));
   mdb_.reset(new std::vector<int>());
   d_.reset(new Impl());
@@ -381,6 +384,12 @@ void QLTHip::run () {
                                        d.b_qm + ti*n, d.b_min + ti*n, d.b_max + ti*n,
                                        d.b_prev ? d.b_prev + ti*n : nullptr, o.l2r_data, s));
   }
+  // The fused top tile (plan::Stage::top), if the plan has one, is the last local stage; the
+  // root->leaves launch over it, cedr_hip_qlt_top, also takes in what precedes it:
+  // root_compute on one rank (mode 1), the apex on several (mode 2).
+  const bool has_top = eng_->has_top();
+  int top_mode = 0;
+  const Real* recv = nullptr;
   if (eng_->level_mode()) {
     // Partial tree / scattered ownership: what this rank owns above its pure subtrees goes level by
     // level with one round of messages per level (reference QLT::run, cedr_qlt.cpp:618-640).
@@ -393,24 +402,41 @@ void QLTHip::run () {
     }
   } else if (eng_->has_apex()) {
     // Ranks own whole subtrees and the tree above them is small: after the local sweeps and the
-    // ONE all-gather, one single-workgroup launch does the replicated top (both directions and
-    // root_compute) and hands this rank's boundary roots their masses.
-    const Real* const recv = eng_->up_to_exchange(d.lay.l2rndps, d.lay.l2r_op, d.l2r, false, s,
-                                                  rows_mode ? d.in_rows.data() : nullptr);
-    cedr_k_check(cedr_hip_qlt_apex(&d.lay, eng_->apex_stage(), recv, eng_->apex_src(), eng_->n_my_roots(),
-                                   eng_->apex_my_in(), eng_->my_root_slots_dev(), d.r2l, s));
+    // ONE all-gather, one launch does the replicated top (both directions and root_compute) and
+    // hands this rank's boundary roots their masses -- the top tile's own launch if there is one.
+    recv = eng_->up_to_exchange(d.lay.l2rndps, d.lay.l2r_op, d.l2r, false, s,
+                                rows_mode ? d.in_rows.data() : nullptr);
+    if (has_top) top_mode = 2;
+    else
+      cedr_k_check(cedr_hip_qlt_apex(&d.lay, eng_->apex_stage(), recv, eng_->apex_src(), eng_->n_my_roots(),
+                                     eng_->apex_my_in(), eng_->my_root_slots_dev(), d.r2l, s));
   } else {
-    eng_->up(d.lay.l2rndps, d.lay.l2r_op, d.l2r, false, s, rows_mode ? d.in_rows.data() : nullptr);
-    cedr_k_check(cedr_hip_qlt_root(&d.lay, eng_->get_plan().root_slot, d.l2r, d.r2l, s));
     const auto& top = eng_->top_stages();
+    // One rank: the top tile's root->leaves launch re-forms the tile's sums and computes the root
+    // itself, so the leaves->root sweep stops below it.
+    const bool fused_root = has_top && top.empty();
+    eng_->up(d.lay.l2rndps, d.lay.l2r_op, d.l2r, false, s, rows_mode ? d.in_rows.data() : nullptr, fused_root);
+    if (fused_root) top_mode = 1;
+    else cedr_k_check(cedr_hip_qlt_root(&d.lay, eng_->get_plan().root_slot, d.l2r, d.r2l, s));
     for (size_t i = top.size(); i > 0; --i)
       cedr_k_check(cedr_hip_qlt_down(&d.lay, &top[i-1]->h, d.l2r, d.r2l, s));
     eng_->top_to_local(d.lay.r2lndps, d.r2l, s);
   }
   const auto& loc = eng_->local_stages();
+  // sweep_down_event(): recorded exactly once per run(), before the launch over the cells
+  if (loc.empty() && d.down_ev) cedr_hip_check(hipEventRecord(d.down_ev, s));
   for (size_t i = loc.size(); i > 0; --i) {
-    const bool rows = rows_mode && i == 1;
     if (i == 1 && d.down_ev) cedr_hip_check(hipEventRecord(d.down_ev, s));
+    if (has_top && i == loc.size()) {
+      const bool apx = top_mode == 2;
+      cedr_k_check(cedr_hip_qlt_top(&d.lay, eng_->top_stage(), eng_->top_tile(), d.l2r, d.r2l, top_mode,
+                                    apx ? eng_->apex_stage() : nullptr, apx ? eng_->apex_tile() : nullptr,
+                                    recv, apx ? eng_->apex_src() : nullptr,
+                                    apx ? eng_->n_my_roots() : 0, apx ? eng_->apex_my_in() : nullptr,
+                                    apx ? eng_->my_root_slots_dev() : nullptr, s));
+      continue;
+    }
+    const bool rows = rows_mode && i == 1;
     cedr_k_check(cedr_hip_qlt_down_rows(&d.lay, &loc[i-1]->h, d.l2r, d.r2l,
                                         rows ? d.in_rows.data() : nullptr,
                                         rows ? d.out_rows.data() : nullptr, nlclcells(), s));

@@ -135,6 +135,29 @@ int cedr_hip_qlt_apex(const cedr_hip_qlt_layout* lay, const cedr_hip_stage* apex
 int cedr_hip_tree_apex_sum(const cedr_hip_stage* apex, const double* recv, const int32_t* src, int32_t nfields,
                            int zero_init, double* out, cedr_stream_t stream);
 
+/* FUSED TOP. The last, latency-bound stages of a rank's forest as one plain tile `top` (a stage of
+ * exactly one tile with up to 2048 inputs, several levels, one output per subtree root of the rank),
+ * swept tracer-parallel in ONE launch per direction instead of one launch per stage.
+ * cedr_hip_tree_top_up: leaves->root over `nfields` fields (any combine rules), one workgroup per 4
+ * fields; writes the tile's outputs to their slots and, if sendbuf != NULL, packs the records of this
+ * rank's nroots boundary roots (slots root_slots[j]) as sendbuf[j*nfields + f] for the all-gather --
+ * the gather_slots launch fused in (cedr_qlt.cpp:432-439).
+ * cedr_hip_qlt_top: root->leaves, one workgroup per tracer: re-forms the tile's sums, gets the outputs'
+ * masses -- mode 0: from their r2l slots; mode 1 (single rank, the tile's one output is the global root):
+ * by root_compute (cedr_qlt.cpp:441-476) on sums that include Qm_prev, so that no leaves->root launch over
+ * the top tile is needed at all; mode 2: from the gathered boundary records through the apex tile, i.e.
+ * cedr_hip_qlt_apex fused in (apex, recv, src, nmine, my_in, my_slot as there) -- and solves every node
+ * problem of the tile (cedr_qlt.cpp:525-604), writing the inputs' masses to their r2l slots.
+ * top_tile / apex_tile: HOST copies of the stages' single tile descriptors (top->tiles[0] is device memory;
+ * the kernels take the descriptor by value so that their first memory access is already the kid table). */
+int cedr_hip_tree_top_up(const cedr_hip_stage* top, const cedr_hip_tile* top_tile, int32_t nfields,
+                         const uint8_t* op, int64_t stride, double* data, int zero_init, int32_t nroots,
+                         const int32_t* root_slots, double* sendbuf, cedr_stream_t stream);
+int cedr_hip_qlt_top(const cedr_hip_qlt_layout* lay, const cedr_hip_stage* top, const cedr_hip_tile* top_tile,
+                     double* l2r, double* r2l, int mode, const cedr_hip_stage* apex,
+                     const cedr_hip_tile* apex_tile, const double* recv, const int32_t* src,
+                     int32_t nmine, const int32_t* my_in, const int32_t* my_slot, cedr_stream_t stream);
+
 /* Boundary exchange helpers (replace the per-level MPI messages of
  * cedr_qlt.cpp:327-337,432-439,478-488,606-613):
  * gather : out[j*nfields + f] = data[f*stride + slots[j]], j < n
@@ -336,6 +359,9 @@ int cedr_plan_summary(void* plan, int64_t* summary8);
  * plan has none). */
 int cedr_plan_stage_sizes(void* plan, int top, int idx, int* sizes6);
 int cedr_plan_stage_micro(void* plan, int top, int idx, uint16_t* micro, uint16_t* outs);
+/* 1 if the stage is the fused top tile (one plain tile of up to 2048 inputs over what is left of the
+ * rank's forest, swept by cedr_hip_tree_top_up / cedr_hip_qlt_top), 0 if not, -1 if there is no such stage */
+int cedr_plan_stage_is_top(void* plan, int top, int idx);
 int cedr_plan_stage(void* plan, int top, int idx, int* tiles_x10, uint16_t* kids, int* lvlptr);
 /* my_root_slots[#my roots], my_top_slots[#my roots], gather_slots[nranks*nb_max] */
 int cedr_plan_exchange(void* plan, int* my_root_slots, int* my_top_slots, int* gather_slots);

@@ -4,6 +4,7 @@
 // every precondition the kernel launchers and kernels rely on (index ranges, LDS
 // bounds, micro-subtree shapes, padding reads). A violated precondition on the GPU
 // would be an out-of-bounds access; here it is a message and a non-zero exit.
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <memory>
@@ -22,7 +23,18 @@ static int g_fail = 0;
 
 static void check_stage (const plan::Stage& st, const plan::Plan& pl, const int64_t stride, const bool first,
                          const char* ctx) {
-  REQUIRE(st.max_nleaf <= 256);
+  if (st.top) {
+    // the top kernels' preconditions (cedr_kernels.hip top_stage_ok): one plain tile, <= 2048 inputs,
+    // <= 4095 nodes, a level has at most nleaf/2 <= 1024 nodes (two per thread in qlt_top_kernel)
+    REQUIRE(st.tiles.size() == 1 && st.micro.empty() && ! first);
+    REQUIRE(st.max_nleaf <= 2048 && st.max_nodes <= 4095);
+    const auto& t = st.tiles[0];
+    for (int l = 0; l < t.nlvl; ++l)
+      REQUIRE(st.lvlptr[t.lvl_off + l + 1] - st.lvlptr[t.lvl_off + l] <= 1024);
+    REQUIRE(t.nint == t.nleaf - t.nout);  // a forest with one output per tree
+  } else {
+    REQUIRE(st.max_nleaf <= 256);
+  }
   const bool micro = ! st.micro.empty();
   if (micro) REQUIRE(st.max_nleaf <= 64);
   std::set<int> out_slots;
@@ -93,7 +105,26 @@ static void check (const tree::FlatTree& t, const int ncells, const int nranks, 
     catch (const std::logic_error&) { continue; }  // orders the planner rejects by design
     REQUIRE(pl.nlcl == nown);
     const int64_t stride = ((int64_t) pl.nslots + 2 + 15)/16*16;
-    for (size_t i = 0; i < pl.local.size(); ++i) check_stage(pl.local[i], pl, stride, i == 0, ctx);
+    for (size_t i = 0; i < pl.local.size(); ++i) {
+      REQUIRE( ! pl.local[i].top || i + 1 == pl.local.size());  // the fused top tile is the last local stage
+      check_stage(pl.local[i], pl, stride, i == 0, ctx);
+    }
+    if ( ! pl.local.empty() && pl.local.back().top) {
+      // its inputs are exactly the previous stage's outputs; on one rank its one output is the root
+      const plan::Stage& prev = pl.local[pl.local.size() - 2];
+      const plan::Tile& tt = pl.local.back().tiles[0];
+      int lo = pl.nslots, hi = -1;
+      for (const auto& q : prev.tiles) { lo = std::min(lo, q.out); hi = std::max(hi, q.out + q.nout); }
+      REQUIRE(tt.in0 == lo && tt.in0 + tt.nleaf == hi);
+      if (nranks == 1) REQUIRE(tt.nout == 1 && tt.out == pl.root_slot);
+      // every output of the tile is one of my boundary roots' slots
+      if (nranks > 1)
+        for (int k = 0; k < tt.nout; ++k) {
+          bool found = false;
+          for (const int s : pl.my_root_slots) found = found || s == tt.out + k;
+          REQUIRE(found);
+        }
+    }
     for (size_t i = 0; i < pl.top.size(); ++i) check_stage(pl.top[i], pl, stride, false, ctx);
     REQUIRE(pl.root_slot >= 0 && pl.root_slot < pl.nslots);
     if ( ! pl.apex.tiles.empty()) {
@@ -145,7 +176,26 @@ static void check_level (const tree::FlatTree& full, const int ncells, const int
     catch (const std::logic_error& e) { std::printf("FAIL %s: rank %d: %s\n", ctx, me, e.what()); ++g_fail; return; }
     REQUIRE(pl.level_mode && pl.top.empty() && pl.apex.tiles.empty());
     const int64_t stride = ((int64_t) pl.nslots + 2 + 15)/16*16;
-    for (size_t i = 0; i < pl.local.size(); ++i) check_stage(pl.local[i], pl, stride, i == 0, ctx);
+    for (size_t i = 0; i < pl.local.size(); ++i) {
+      REQUIRE( ! pl.local[i].top || i + 1 == pl.local.size());  // the fused top tile is the last local stage
+      check_stage(pl.local[i], pl, stride, i == 0, ctx);
+    }
+    if ( ! pl.local.empty() && pl.local.back().top) {
+      // its inputs are exactly the previous stage's outputs; on one rank its one output is the root
+      const plan::Stage& prev = pl.local[pl.local.size() - 2];
+      const plan::Tile& tt = pl.local.back().tiles[0];
+      int lo = pl.nslots, hi = -1;
+      for (const auto& q : prev.tiles) { lo = std::min(lo, q.out); hi = std::max(hi, q.out + q.nout); }
+      REQUIRE(tt.in0 == lo && tt.in0 + tt.nleaf == hi);
+      if (nranks == 1) REQUIRE(tt.nout == 1 && tt.out == pl.root_slot);
+      // every output of the tile is one of my boundary roots' slots
+      if (nranks > 1)
+        for (int k = 0; k < tt.nout; ++k) {
+          bool found = false;
+          for (const int s : pl.my_root_slots) found = found || s == tt.out + k;
+          REQUIRE(found);
+        }
+    }
     REQUIRE(pl.root_slot >= 0 && pl.root_slot < pl.nslots && pl.root_owner >= 0 && pl.root_owner < nranks);
     std::vector<char> have(pl.nslots, 0);
     for (int i = 0; i < pl.nlcl; ++i) have[i] = 1;

@@ -276,10 +276,12 @@ def test_plan_invariants(ca, tile):
     assert pl["nlcl"] == nc
     seen = np.zeros(pl["nslots"], np.int32)
     covered = np.zeros(pl["nslots"], np.int32)
-    for st in pl["local"]:
+    for si, st in enumerate(pl["local"]):
+        # the fused top tile: one plain tile of up to 2048 inputs, only ever the last stage
+        assert not st["top"] or (si == len(pl["local"]) - 1 and si > 0 and len(st["tiles"]) == 1)
         for t in st["tiles"]:
             in0, nleaf, out, nint, koff, loff, nlvl = [int(x) for x in t[:7]]
-            assert 1 <= nleaf <= tile and nint == nleaf - 1
+            assert 1 <= nleaf <= (2048 if st["top"] else tile) and nint == nleaf - 1
             assert int(t[8]) == 1 and st["outs"][int(t[9])] == nleaf + nint - 1  # one output: the root
             covered[in0:in0 + nleaf] += 1
             seen[out] += 1
@@ -304,13 +306,23 @@ def test_micro_plan_invariants(ca, imbalanced):
     pl = ca.Tree.make_1d(nc, 1, False, imbalanced).plan(nc, 0, 1, 0)
     want = set(range(nc))  # slots the stage must consume
     assert len(pl["local"]) >= 2
+    assert pl["local"][-1]["top"]  # 5000 cells: one micro stage, then the fused top tile
     for si, st in enumerate(pl["local"]):
+        if st["top"]:
+            # The fused top tile: ONE plain tile whose inputs are exactly the previous stage's outputs
+            # (consecutive slots) and whose one output is the root.
+            assert si == len(pl["local"]) - 1 and len(st["tiles"]) == 1 and len(st["micro"]) == 0
+            in0, nleaf, out, nint, koff, loff, nlvl, moff, nout, ooff = [int(x) for x in st["tiles"][0]]
+            assert nleaf <= 2048 and nint == nleaf - nout and nout == 1
+            assert set(range(in0, in0 + nleaf)) == want
+            want = set(range(out, out + nout))
+            continue
         assert len(st["micro"]) > 0
         got, produced = [], set()
         for t in st["tiles"]:
             in0, nleaf, out, nint, koff, loff, nlvl, moff, nout, ooff = [int(x) for x in t]
             assert 1 <= nleaf <= 64 and nint == nleaf - nout
-            assert nlvl <= 2 if si <= 1 else nout == 1  # only the first two stages cut their tiles (to 2 levels)
+            assert nlvl <= 2  # with a fused top every micro stage cuts its tiles (to 2 levels)
             outs = st["outs"][ooff:ooff + nout]
             assert len(set(outs)) == nout and (outs < nleaf + nint).all()
             prev_end = 0

@@ -66,12 +66,14 @@ SMALL = ["--steps", "2", "--warmup", "1", "--ncells", "30000", "--ntracers", "6"
          "--no-cpu-baseline"]
 
 
-@pytest.mark.parametrize("nranks", [2, 3])
-def test_bench_self_spawned_ranks_same_gpu(gpu, nranks):
-    """`python bench.py --gpus N` exactly as typed: bench.py starts its own rank processes."""
-    res, d = _bench(["--gpus", str(nranks), "--comm", "gloo"] + SMALL)
+@pytest.mark.parametrize("nranks,extra", [(2, []), (3, []), (2, ["--serial"])])
+def test_bench_self_spawned_ranks_same_gpu(gpu, nranks, extra):
+    """`python bench.py --gpus N` exactly as typed: bench.py starts its own rank processes. N > 1 runs
+    the two CDRs on two streams by default; --serial puts them back to back on one."""
+    res, d = _bench(["--gpus", str(nranks), "--comm", "gloo"] + SMALL + extra)
     assert res.returncode == 0, res.stdout[-1500:] + res.stderr[-1500:]
     assert d["n_gpus"] == nranks and d["check_ok"] is True and d["scaling"] == "strong"
+    assert d["config"]["streams"] == (1 if extra else 2)
     assert d["config"]["rccl_nranks"] == 0 and d["config"]["transport"].startswith("gloo-host-staged")
 
 

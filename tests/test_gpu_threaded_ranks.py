@@ -223,19 +223,26 @@ def test_bfb_level_mode_ranks_as_threads(gpu, oracle, nranks, ncell, transpose):
         assert np.array_equal(got[r], want), r
 
 
-def test_level_mode_needs_point_to_point(gpu):
-    """A transport without the exchange callback runs all-gather plans only: a level-mode plan
-    fails with a message, not with wrong numbers."""
+def test_level_mode_needs_point_to_point(gpu, monkeypatch):
+    """A transport without the exchange callback (mpi::Comm::has_exchange false) runs all-gather plans
+    only. A partial tree needs the per-level messages: refused when the CDR is CONSTRUCTED, on every
+    rank alike, not at the first level step inside run(). A full tree with scattered ownership, which
+    the planner would otherwise put in level mode, is planned for the all-gather instead."""
     ca = gpu
     bad = lambda *a: 1
-    tree = ca.Tree.make_1d(64, 2).prune(0)
-    q = ca.QLT(ca.Parallel.callbacks(0, 2, bad, bad), 64, tree)
+    with pytest.raises(ca.CedrError, match="point-to-point"):
+        ca.QLT(ca.Parallel.callbacks(0, 2, bad, bad), 64, ca.Tree.make_1d(64, 2).prune(0))
+    monkeypatch.setenv("CEDR_HIP_EXCHANGE", "2")
+    with pytest.raises(ca.CedrError, match="point-to-point"):
+        ca.QLT(ca.Parallel.callbacks(0, 2, bad, bad), 64, ca.Tree.make_1d(64, 2))
+    monkeypatch.delenv("CEDR_HIP_EXCHANGE")
+    nc = 40000  # pseudorandom ownership: level mode by the planner's own rule ...
+    assert ca.Tree.make_1d(nc, 4, True, False).plan(nc, 1, 4, 0)["level_mode"]
+    q = ca.QLT(ca.Parallel.callbacks(1, 4, bad, bad), nc, ca.Tree.make_1d(nc, 4, True, False))
     q.declare_tracer(7, 0)
     q.end_tracer_declarations()
     q.finish_setup()
-    assert q.plan()["level_mode"]
-    with pytest.raises(ca.CedrError, match="point-to-point"):
-        q.run()
+    assert not q.plan()["level_mode"]  # ... but not over a transport that cannot exchange
 
 
 @pytest.mark.parametrize("kind,nleaf,nranks,how,pin", [

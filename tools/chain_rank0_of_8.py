@@ -29,9 +29,11 @@ for q in (qa, qb):
     st = torch.cuda.Stream(device=dev); q.set_stream(st.cuda_stream)
 print('single rank, 187.5k cells : %.4f ms' % timeit(qa.run))
 print('rank 0 of 8, 1.5M cells   : %.4f ms' % timeit(qb.run))
-ca.profile_start()
-for _ in range(20): qb.run()
-recs = ca.profile_stop()
-agg = {}
-for name, aux, ms in recs: agg.setdefault((name, aux), []).append(ms)
-for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])): print('  %-24s %-8d %.4f ms' % (k[0], k[1], sum(v)/len(v)))
+for label, q in (("single rank, 187.5k cells", qa), ("rank 0 of 8, 1.5M cells", qb)):
+    ca.profile_start()
+    for _ in range(20): q.run()
+    recs = ca.profile_stop()
+    agg = {}
+    for name, aux, ms in recs: agg.setdefault((name, aux), []).append(ms)
+    print(label + ", per launch (HIP events):")
+    for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])): print('  %-24s %-8d %.4f ms' % (k[0], k[1], sum(v)/len(v)))
