@@ -1214,7 +1214,7 @@ void qlt_down_sp_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st,
         double* K0 = R + 4*c0;
         double* K1 = R + 4*c1;
         double x0, x1;
-        node_problem_mass(P[0], P[1], P[2], P[3], r0, K0[0], K0[1], K0[2], r1, K1[0], K1[1], K1[2],
+        node_problem_mass_wave(P[0], P[1], P[2], P[3], r0, K0[0], K0[1], K0[2], r1, K1[0], K1[1], K1[2],
                           x0, x1, prefer);
         K0[3] = x0;
         K1[3] = x1;
@@ -1240,16 +1240,16 @@ void qlt_down_sp_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st,
       if ((any2 && m.shape == 2) || (any3 && m.shape == 3)) {
         const KidRho kp{cellrho[6*kWave + lane], cellrho[7*kWave + lane], cellrho[8*kWave + lane]};
         if (any2 && m.shape == 2)
-          node_problem_mass(RR[0], RR[1], RR[2], Xr, kt, T[0], T[1], T[2],
+          node_problem_mass_wave(RR[0], RR[1], RR[2], Xr, kt, T[0], T[1], T[2],
                             kp, cur[s][2][0], cur[s][2][1], cur[s][2][2], Xt, Xp, prefer);
         if (any3 && m.shape == 3)
-          node_problem_mass(RR[0], RR[1], RR[2], Xr, kp, cur[s][2][0], cur[s][2][1], cur[s][2][2],
+          node_problem_mass_wave(RR[0], RR[1], RR[2], Xr, kp, cur[s][2][0], cur[s][2][1], cur[s][2][2],
                             kt, T[0], T[1], T[2], Xp, Xt, prefer);
       }
       if (m.shape >= 1) {
         const KidRho ku{cellrho[0*kWave + lane], cellrho[1*kWave + lane], cellrho[2*kWave + lane]};
         const KidRho kv{cellrho[3*kWave + lane], cellrho[4*kWave + lane], cellrho[5*kWave + lane]};
-        node_problem_mass(T[0], T[1], T[2], Xt, ku, cur[s][0][0], cur[s][0][1], cur[s][0][2],
+        node_problem_mass_wave(T[0], T[1], T[2], Xt, ku, cur[s][0][0], cur[s][0][1], cur[s][0][2],
                           kv, cur[s][1][0], cur[s][1][1], cur[s][1][2], Xu, Xv, prefer);
       }
       double* __restrict__ const orow = (ROWS ? outL[biw] : r2l + static_cast<size_t>(r2lL[biw])*S) + tile.in0;
@@ -2413,6 +2413,7 @@ int set_lds_limit (K kernel, size_t bytes) {
 # define CEDR_UP_FT 16
 #endif
 constexpr int kUpFT = CEDR_UP_FT;
+constexpr int kUpFT32MaxTiles = 0;  // stages of at most this many tiles take 32 fields per chunk (0: none)
 constexpr int kDownTT = 8;   // tracers per chunk, root->leaves
 
 // kid pairs (4 B each) + level offsets (4 B each), rounded up to doubles
@@ -2462,13 +2463,19 @@ int cedr_hip_tree_up_rows_sums (const cedr_hip_stage* st, int32_t nfields, const
   if (st->max_nleaf > 256) return static_cast<int>(hipErrorInvalidValue);
   if (in_rows && ( ! st->micro || nrow < 3)) return static_cast<int>(hipErrorInvalidValue);
   const int pitch = pitch_for(st->max_nodes);
-  const size_t lds0 = sizeof(double)*(meta_doubles(st) + static_cast<size_t>(kUpFT)*pitch) +
+  // Stages of few tiles (one round of workgroups or less) are bound by the latency of a chunk, not by
+  // occupancy: they take 32 fields per chunk -- half the chunks, twice the loads in flight per wave.
+  static const int ft32_max = [] { const char* v = std::getenv("CEDR_HIP_UP_FT32"); return v ? std::atoi(v) : kUpFT32MaxTiles; }();
+  const bool ft32 = st->micro && ! in_rows && st->ntiles <= ft32_max;
+  const int FTr = ft32 ? 32 : kUpFT;
+  const size_t lds0 = sizeof(double)*(meta_doubles(st) + static_cast<size_t>(FTr)*pitch) +
     (in_rows ? sizeof(double*)*static_cast<size_t>(nfields) : 0) +   // row table
     sizeof(int32_t)*static_cast<size_t>(nfields + 2 + kWave);  // + op table, + output node ids
   static const size_t lds_pad = [] { const char* v = std::getenv("CEDR_HIP_UP_LDS_PAD"); return v ? static_cast<size_t>(std::atol(v)) : 0; }();
   const size_t lds = lds0 + lds_pad;  // (experiments: extra LDS bytes per workgroup lower the occupancy)
   if (lds > 160*1024) return static_cast<int>(hipErrorInvalidValue);
-  const dim3 grid(st->ntiles, chunk_split(st->ntiles, (nfields + kUpFT - 1)/kUpFT, kSplitUp));
+  static const int split_up = [] { const char* v = std::getenv("CEDR_HIP_SPLIT_UP"); return v ? std::atoi(v) : kSplitUp; }();
+  const dim3 grid(st->ntiles, chunk_split(st->ntiles, (nfields + FTr - 1)/FTr, split_up));
   const dim3 gridx(xcd_grid(st->ntiles), grid.y);  // micro kernels: XCD-contiguous tile ranges
 #ifdef CEDR_DIAG_UP_BLOCKSTORE2
   {
@@ -2494,7 +2501,8 @@ int cedr_hip_tree_up_rows_sums (const cedr_hip_stage* st, int32_t nfields, const
     };
     const bool sums = all_sums && ! zero_init;
     int e;
-    if (in_rows) e = sums ? go(tree_up_micro_kernel<kUpFT, true, true>) : go(tree_up_micro_kernel<kUpFT, true, false>);
+    if (ft32) e = sums ? go(tree_up_micro_kernel<32, false, true>) : go(tree_up_micro_kernel<32, false, false>);
+    else if (in_rows) e = sums ? go(tree_up_micro_kernel<kUpFT, true, true>) : go(tree_up_micro_kernel<kUpFT, true, false>);
     else e = sums ? go(tree_up_micro_kernel<kUpFT, false, true>) : go(tree_up_micro_kernel<kUpFT, false, false>);
     if (e) return e;
   } else if (st->max_nleaf <= 128) {

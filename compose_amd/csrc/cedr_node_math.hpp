@@ -15,15 +15,26 @@ namespace cedr_dev {
 constexpr double kEps = DBL_EPSILON;
 enum : int { CONSERVE = 1, SHAPEPRESERVE = 2, CONSISTENT = 4, NONNEGATIVE = 8 };
 
+// Whether any lane of the wave (that is active here) has p set. Host builds (tests/cpp/np_wave_check.cpp)
+// see a wave of one lane.
+#ifndef CEDR_NP_TRACE  // (tests/cpp/np_wave_check.cpp counts which way a problem went)
+# define CEDR_NP_TRACE(code)
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+# define CEDR_WAVE_ANY(p) (__ballot(p) != 0)
+#else
+# define CEDR_WAVE_ANY(p) (p)
+#endif
+
 // reference cedr_kokkos.hpp:136-139: comparisons, not fmin/fmax.
-__device__ __forceinline__ double rmin (double a, double b) { return a < b ? a : b; }
-__device__ __forceinline__ double rmax (double a, double b) { return a > b ? a : b; }
+__host__ __device__ __forceinline__ double rmin (double a, double b) { return a < b ? a : b; }
+__host__ __device__ __forceinline__ double rmax (double a, double b) { return a > b ? a : b; }
 
 // ------------------------------------------------------------------ node math
 // The part of solve_1eq_bc_qp_2d (reference cedr_local_inl.hpp:99-165, a = (1, 1)) that runs when
 // the optimum of the unconstrained problem is outside the box: the solution sits where the
 // line x0 + x1 = b crosses one of the box edges.
-__device__ __forceinline__
+__host__ __device__ __forceinline__
 void qp_edges (const double w0, const double w1, const double b,
                const double lo0, const double lo1, const double hi0, const double hi1,
                const double y0, const double y1, const bool clip, double& x0, double& x1) {
@@ -93,7 +104,7 @@ void qp_edges (const double w0, const double w1, const double b,
 // so every remaining operation sees the same operands in the same order.
 // w_i = 1/rhom_i and q_i = a_i/w_i = 1/w_i depend only on the node, not on the
 // tracer, so the caller computes them once per node and passes them in.
-__device__ void qp_2d (const double w0, const double w1, const double q0, const double q1,
+__host__ __device__ inline void qp_2d (const double w0, const double w1, const double q0, const double q1,
                        const double b,
                        const double lo0, const double lo1, const double hi0, const double hi1,
                        const double y0, const double y1, double& x0, double& x1,
@@ -130,7 +141,7 @@ __device__ void qp_2d (const double w0, const double w1, const double q0, const 
 }
 
 // reference cedr_qlt_inl.hpp:69-99 (r2l_nl_adjust_bounds)
-__device__ void adjust_bounds (double& b0, double& b1, const double rh0, const double rh1,
+__host__ __device__ inline void adjust_bounds (double& b0, double& b1, const double rh0, const double rh1,
                                const double extra) {
   const double q0 = b0/rh0, q1 = b1/rh1;
   if (extra < 0) {
@@ -152,7 +163,7 @@ __device__ void adjust_bounds (double& b0, double& b1, const double rh0, const d
 // reference cedr_qlt_inl.hpp:120-173 (mass form of the node problem)
 struct KidRho { double rh, w, q; };  // rhom, 1/rhom, 1/(1/rhom) of a kid
 
-__device__ void node_problem_mass (const double p_lo, const double p_orig, const double p_hi,
+__host__ __device__ inline void node_problem_mass (const double p_lo, const double p_orig, const double p_hi,
                                    const double Qm,
                                    const KidRho r0, double lo0, const double or0, double hi0,
                                    const KidRho r1, double lo1, const double or1, double hi1,
@@ -177,6 +188,115 @@ __device__ void node_problem_mass (const double p_lo, const double p_orig, const
   x0 = or0;
   x1 = or1;
   qp_2d(r0.w, r1.w, r0.q, r1.q, Qm, lo0, lo1, hi0, hi1, or0, or1, x0, x1, ! prefer, ! prefer);
+}
+
+// The same node problem (bit-identical results) written for how a wave executes it. The lanes of a
+// wave almost never agree on which way node_problem_mass branches, so the wave runs both sides of
+// nearly every `if`, and every divergent branch costs a saveexec / branch / restore sequence and a
+// fetch bubble on top. Here the COMMON case -- the node's mass inside its bounds, which is every node
+// of a feasible problem -- is straight-line code: all candidate results (keep the kids' masses; the
+// corner exits of check_lu; the unconstrained optimum; the better of the two box-edge intersections)
+// are computed unconditionally and picked by selects. Two wave-uniform branches remain: past the
+// box-edge part when no lane needs it (real data: most nodes), and to node_problem_mass itself, for the
+// whole wave, when ANY lane is in a case the straight-line code does not cover (an infeasible node,
+// which adjusts bounds; a degenerate box whose edge intersections do not separate).
+//
+// The box-edge part replaces qp_edges' twelve comparisons by four, using what the reference's scan
+// (cedr_local_inl.hpp:121-147: first minimum and first maximum of the four alphas, the two remaining
+// edges in index order) gives whenever the minimum is al0 or al1 (al0 if equal: the FIRST minimum) and
+// the maximum is al2 or al3 (al2 if equal): the remaining edges are m0 = (al0 > al1 ? 0 : 1) and
+// m1 = (al2 < al3 ? 2 : 3), m0 < m1. Any box the line x0 + x1 = Qm really crosses is like that;
+// otherwise: the general routine.
+__host__ __device__ __forceinline__
+void node_problem_mass_wave (const double p_lo, const double p_orig, const double p_hi, const double Qm,
+                             const KidRho r0, const double lo0, const double or0, const double hi0,
+                             const KidRho r1, const double lo1, const double or1, const double hi1,
+                             double& x0, double& x1, const bool prefer) {
+#ifdef CEDR_DIAG_NOQP
+  x0 = or0; x1 = or1; return;
+#endif
+#ifdef CEDR_NP_GENERAL  // (experiments: the branchy routine everywhere)
+  node_problem_mass(p_lo, p_orig, p_hi, Qm, r0, lo0, or0, hi0, r1, lo1, or1, hi1, x0, x1, prefer);
+  return;
+#endif
+  const bool outside = Qm < p_lo || Qm > p_hi;
+  const bool quick = Qm == p_orig && or0 >= lo0 && or0 <= hi0 && or1 >= lo1 && or1 <= hi1;
+  if ( ! CEDR_WAVE_ANY(outside || ! quick)) {  // every lane keeps its kids' masses (unperturbed data)
+    x0 = or0; x1 = or1;
+    CEDR_NP_TRACE(1);
+    return;
+  }
+  // check_lu's corner exits (only with early_exit_on_tol = ! prefer)
+  bool exl = false, exh = false;
+  if ( ! prefer) {
+    const double ab = fmax(fmax(fabs(Qm), fabs(or0)), fabs(or1));
+    const double r_tol = 1e1*kEps*ab;
+    double r = -Qm;
+    r += lo0; r += lo1;
+    double r2 = -Qm;
+    r2 += hi0; r2 += hi1;
+    const bool out = ! (fabs(r) <= r_tol);
+    exl = out && r > 0;
+    exh = out && ! (r > 0) && ! (fabs(r2) <= r_tol) && r2 < 0;
+  }
+  // unconstrained optimum
+  const double qmass = r0.q + r1.q;
+  double dm = Qm;
+  dm -= or0; dm -= or1;
+  const double lambda = dm/qmass;
+  const double xa = or0 + lambda*r0.q;
+  const double xb = or1 + lambda*r1.q;
+  const bool inside = ! (xa < lo0 || xa > hi0) && ! (xb < lo1 || xb > hi1);
+  const bool done = quick || exl || exh || inside;
+  double e0 = 0, e1 = 0;
+  bool general = outside;
+  if (CEDR_WAVE_ANY( ! done && ! outside)) {
+    const double base = 0.5*Qm;
+    const double al0 = lo1 - base;      // bottom: x1 = lo1
+    const double al1 = -(hi0 - base);   // right:  x0 = hi0
+    const double al2 = hi1 - base;      // top:    x1 = hi1
+    const double al3 = -(lo0 - base);   // left:   x0 = lo0
+    const bool c01 = al0 > al1, c23 = al2 < al3;
+    const double a_lo = c01 ? al0 : al1, a_hi = c23 ? al2 : al3;    // the kept pair
+    const double a_min = c01 ? al1 : al0, a_max = c23 ? al3 : al2;  // the dropped pair
+    // The scan drops exactly these two iff the FIRST minimum of the four is the dropped lower one
+    // (a_min <= a_hi; a_min <= a_lo and a_hi <= a_max hold by construction) and the FIRST maximum is the
+    // dropped upper one (a_max > a_lo, strictly: a tie would make index 0 or 1 the first maximum).
+    // A node sitting exactly on a bound -- common: every box-edge solution puts a kid there -- has
+    // a_lo == a_hi up to rounding and still passes.
+    general = general || ( ! done && ! (a_min <= a_hi && a_max > a_lo));
+    double obj0, obj1;
+    {
+      const double t0 = base - a_lo, t1 = base + a_lo;
+      const double d0 = or0 - t0, d1 = or1 - t1;
+      obj0 = r0.w*(d0*d0) + r1.w*(d1*d1);
+    }
+    {
+      const double t0 = base - a_hi, t1 = base + a_hi;
+      const double d0 = or0 - t0, d1 = or1 - t1;
+      obj1 = r0.w*(d0*d0) + r1.w*(d1*d1);
+    }
+    const bool pick0 = obj0 <= obj1;
+    const bool fixed1 = pick0 ? c01 : c23;  // x1 sits on its bound, else x0 does
+    const double v_lo = c01 ? lo1 : hi0, v_hi = c23 ? hi1 : lo0;
+    const double v = pick0 ? v_lo : v_hi;
+    double other = Qm - v;
+    if ( ! prefer) {
+      const double lo_o = fixed1 ? lo0 : lo1, hi_o = fixed1 ? hi0 : hi1;
+      other = rmin(hi_o, rmax(lo_o, other));
+    }
+    e0 = fixed1 ? other : v;
+    e1 = fixed1 ? v : other;
+  }
+  if (CEDR_WAVE_ANY(general)) {
+    CEDR_NP_TRACE(0);
+    node_problem_mass(p_lo, p_orig, p_hi, Qm, r0, lo0, or0, hi0, r1, lo1, or1, hi1, x0, x1, prefer);
+    return;
+  }
+  CEDR_NP_TRACE(quick ? 1 : (exl || exh ? 2 : (inside ? 3 : 4)));
+  // in the order in which node_problem_mass / qp_2d decide
+  x0 = quick ? or0 : (exl ? lo0 : (exh ? hi0 : (inside ? xa : e0)));
+  x1 = quick ? or1 : (exl ? lo1 : (exh ? hi1 : (inside ? xb : e1)));
 }
 
 // N independent node problems of one lane advanced in LOCKSTEP: the same operations on the same
