@@ -41,6 +41,7 @@ TreeEngine::TreeEngine (const mpi::Parallel::Ptr& p, const tree::FlatTree& t,
                         const tree::NodeSets& ns, const plan::Options& opt)
   : p_(p)
 {
+  util::PhaseTimer ptm;
   // Local cell index of every owned leaf = its NodeSets offset (the reference's
   // numbering, visible to callers through get_owned_glblcells).
   util::IdMap gci2lci;
@@ -71,7 +72,9 @@ TreeEngine::TreeEngine (const mpi::Parallel::Ptr& p, const tree::FlatTree& t,
                   "third callback, use RCCL, or the MPI adapter");
     popt.exchange = 1;
   }
+  ptm.lap("engine: leaf slots");
   plan_ = plan::build(t, me, p->size(), leaf_slot, popt);
+  ptm.lap("engine: plan::build");
   // Rounded up to 16 doubles (128-byte rows) with at least two spare slots per
   // row: the kernels' 16-byte cell loads may read up to two slots past a tile.
   stride_ = (static_cast<int64_t>(plan_.nslots) + 2 + 15)/16*16;

@@ -746,8 +746,11 @@ constexpr int kPrioLoads = CEDR_PRIO_LOADS, kPrioLdsLevels = CEDR_PRIO_LDS;  // 
 constexpr int kCellRho = 12;  // LDS doubles per micro-subtree: {rh, w, q} of u, v, p, t
 // ROWS (zero-copy mode, first stage): the cells' input rows come from in_rows[l2r field]
 // and their results go to out_rows[bulk tracer index] instead of l2r / r2l rows.
+#ifndef CEDR_MICRO_WAVES1
+# define CEDR_MICRO_WAVES1 3  // ... and for its one-tracer-per-wave build
+#endif
 template <int TW, bool ROWS>
-__global__ __launch_bounds__(kBlock, CEDR_MICRO_WAVES)
+__global__ __launch_bounds__(kBlock, TW == 1 ? CEDR_MICRO_WAVES1 : CEDR_MICRO_WAVES)
 void qlt_down_micro_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st,
                             double* __restrict__ l2r, double* __restrict__ r2l,
                             const double* const* __restrict__ in_rows,

@@ -5,6 +5,9 @@
 #include "cedr_tree.hpp"
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <set>
 #include <sstream>
 #include <utility>
@@ -12,6 +15,18 @@
 #include "cedr_util.hpp"
 
 namespace cedr {
+namespace util {
+double PhaseTimer::now () {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+PhaseTimer::PhaseTimer () : on_(std::getenv("CEDR_SETUP_TIMES") != nullptr), t0_(on_ ? now() : 0) {}
+void PhaseTimer::lap (const char* label) {
+  if ( ! on_) return;
+  const double t = now();
+  std::fprintf(stderr, "  [setup] %-28s %.3f s\n", label, t - t0_);
+  t0_ = t;
+}
+}  // namespace util
 namespace tree {
 
 Int FlatTree::add (Int parent_idx) {
@@ -136,7 +151,9 @@ typedef std::pair<Int,Int> RankNode;  // (rank, NodeSets node index)
 void init_offsets (const Int my_rank, NodeSets& ns, std::vector<RankNode>& rns,
                    std::vector<NodeSets::Level::MPIMetaData>& mmds, Int& offset) {
   for (auto& rn : rns) if (rn.first == my_rank) rn.first = -1;
-  std::sort(rns.begin(), rns.end());
+  // (a rank's own nodes are listed in allocation order, i.e. already sorted: on one rank, and for
+  // every big level of many, the O(n) check replaces the sort)
+  if ( ! std::is_sorted(rns.begin(), rns.end())) std::sort(rns.begin(), rns.end());
   Int prev_rank = -1;
   for (const auto& rn : rns) {
     NodeSets::Node* const nd = ns.node_h(rn.second);
@@ -176,10 +193,12 @@ void init_comm (const Int my_rank, NodeSets& ns) {
 NodeSets::ConstPtr analyze (const Int my_rank, const Int& ncells, FlatTree t) {
   cedr_throw_if(t.size() == 0, "empty tree");
   cedr_throw_if(t.parent[0] != -1, "tree root has a parent");
+  util::PhaseTimer pt;
   const auto nodesets = std::make_shared<NodeSets>();
   NodeSets& ns = *nodesets;
   const std::vector<Int> order = post_order(t);
   const Int nn = t.size();
+  pt.lap("analyze: post_order");
 
   // reference cedr_tree.cpp:37-53 (init_tree): depth, ranks of internal nodes,
   // ids of internal nodes in post-order starting at ncells.
@@ -201,6 +220,7 @@ NodeSets::ConstPtr analyze (const Int my_rank, const Int& ncells, FlatTree t) {
   Int depth = height[0];
   if (t.level[0] >= 0) depth = t.level[0] + 1;
   ns.levels.resize(depth);
+  pt.lap("analyze: init_tree");
 
   // reference cedr_tree.cpp:55-129 (level_schedule_and_collect), post-order.
   {  // one allocation for the node pool: owned nodes + one placeholder per remote kid at most
@@ -264,6 +284,7 @@ NodeSets::ConstPtr analyze (const Int my_rank, const Int& ncells, FlatTree t) {
     }
   }
 
+  pt.lap("analyze: level schedule");
   {  // reference cedr_tree.cpp:138-144 (consolidate)
     std::vector<NodeSets::Level> keep;
     for (auto& level : ns.levels)
@@ -271,6 +292,7 @@ NodeSets::ConstPtr analyze (const Int my_rank, const Int& ncells, FlatTree t) {
     ns.levels.swap(keep);
   }
   init_comm(my_rank, ns);
+  pt.lap("analyze: init_comm");
   return nodesets;
 }
 

@@ -40,6 +40,8 @@ namespace util {
 // 6x smaller, with the same lookups.
 class IdMap {
   std::vector<std::pair<int,int> > v_;
+  std::vector<int> dense_;  // a rank's ids are usually one block with few gaps: then a direct table
+  long lo_ = 0;             // ... of ids lo_ .. lo_ + dense_.size() - 1
   bool sorted_ = true;
 public:
   void reserve (size_t n) { v_.reserve(n); }
@@ -47,13 +49,39 @@ public:
     if ( ! v_.empty() && id <= v_.back().first) sorted_ = false;
     v_.emplace_back(id, idx);
   }
-  void finish () { if ( ! sorted_) { std::sort(v_.begin(), v_.end()); sorted_ = true; } }
-  size_t size () const { return v_.size(); }
+  void finish () {
+    if (v_.empty()) return;
+    long lo = v_[0].first, hi = lo;
+    for (const auto& e : v_) { lo = std::min<long>(lo, e.first); hi = std::max<long>(hi, e.first); }
+    if (hi - lo < 4*static_cast<long>(v_.size()) + 1024) {
+      lo_ = lo;
+      dense_.assign(static_cast<size_t>(hi - lo) + 1, -1);
+      for (const auto& e : v_) dense_[e.first - lo] = e.second;
+      std::vector<std::pair<int,int> >().swap(v_);
+      sorted_ = true;
+      return;
+    }
+    if ( ! sorted_) { std::sort(v_.begin(), v_.end()); sorted_ = true; }
+  }
+  size_t size () const { return dense_.empty() ? v_.size() : dense_.size(); }
   // -1 if absent
   int find (int id) const {
+    if ( ! dense_.empty()) {
+      const long k = static_cast<long>(id) - lo_;
+      return (k >= 0 && static_cast<size_t>(k) < dense_.size()) ? dense_[k] : -1;
+    }
     const auto it = std::lower_bound(v_.begin(), v_.end(), std::make_pair(id, -1));
     return (it != v_.end() && it->first == id) ? it->second : -1;
   }
+};
+// Setup-phase timing for tools/setup_time.py: CEDR_SETUP_TIMES=1 prints "label seconds" lines to stderr.
+class PhaseTimer {
+  bool on_;
+  double t0_;
+  static double now ();
+public:
+  PhaseTimer ();
+  void lap (const char* label);
 };
 }  // namespace util
 }  // namespace cedr

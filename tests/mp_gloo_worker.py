@@ -28,7 +28,7 @@ def worker(rank, world, initfile, nc, pseudorandom, use_apex, partial=False):
     tree = ca.Tree.make_1d(nc, world, pseudorandom, False)
     if partial:  # every rank passes only its part of the tree -> per-level send / recv
         tree = tree.prune(rank)
-    q = ca.QLT(ca.Parallel.callbacks(rank, world, bad, bad), nc, tree)
+    q = ca.QLT(ca.Parallel.callbacks_p2p(rank, world, bad, bad, bad), nc, tree)
     for t in types:
         q.declare_tracer(t, 0)
     q.end_tracer_declarations()

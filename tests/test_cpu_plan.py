@@ -22,7 +22,9 @@ def planning_parallel(ca, rank, size):
     if size == 1:
         return ca.Parallel.self_()
     bad = lambda *a: 1  # planning never communicates
-    return ca.Parallel.callbacks(rank, size, bad, bad)
+    # (with the third callback: a transport without point-to-point exchange plans every full tree for
+    # the all-gather and refuses partial trees)
+    return ca.Parallel.callbacks_p2p(rank, size, bad, bad, bad)
 
 
 def make_rank(ca, nc, P, r, tree_args, types, tile=None, monkeypatch=None):
