@@ -71,6 +71,7 @@ void BfbTreeAllReducerHip::set_stream (hipStream_t stream) { m_->stream = stream
 void BfbTreeAllReducerHip::finish_setup () {
   if (m_->bd.size()) return;
   eng_->upload();
+  eng_->reserve_exchange(nfield_);
   m_->bd.alloc_zero(static_cast<size_t>(nfield_)*eng_->stride());
   // send's i-th leaf is levels[0].nodes[i] (cedr_bfb_tree_allreduce.cpp:91-102).
   std::vector<int32_t> ls(nlocal_);

@@ -173,11 +173,28 @@ void TreeEngine::up (int32_t nfields, const uint8_t* op_dev, double* data, bool 
 }
 
 void TreeEngine::size_exchange_buffers (int32_t nfields) {
-  const int32_t P = plan_.nranks, nb = plan_.nb_max;
-  if (nfields > xfields_) {
+  if (nfields <= xfields_) return;
+  if (plan_.level_mode) {
+    size_t most = 1;
+    for (const auto& s : plan_.steps) most = std::max(most, std::max(s.out_slots.size(), s.in_slots.size()));
+    sendbuf_.alloc_zero(most*nfields);
+    recvbuf_.alloc_zero(most*nfields);
+    ops_.reserve(2*static_cast<size_t>(plan_.nranks));
+  } else {
+    const int32_t P = plan_.nranks, nb = plan_.nb_max;
     sendbuf_.alloc_zero(static_cast<size_t>(nb)*nfields);
     recvbuf_.alloc_zero(static_cast<size_t>(P)*nb*nfields);
-    xfields_ = nfields;
+  }
+  xfields_ = nfields;
+}
+
+void TreeEngine::reserve_exchange (int32_t nfields) {
+  if (plan_.nranks <= 1) return;
+  size_exchange_buffers(nfields);
+  if (plan_.level_mode && static_cast<size_t>(nfields)*plan_.nranks > bcast_.size()) {  // bcast_root's buffers
+    bcast_.alloc_zero(static_cast<size_t>(nfields)*plan_.nranks);
+    bcast_send_.alloc_zero(nfields);
+    root_slot_dev_.upload(std::vector<int32_t>(1, plan_.root_slot));
   }
 }
 
@@ -229,19 +246,14 @@ void TreeEngine::level_exchange (int32_t i, bool down, int32_t nfields, double* 
   const auto& send_msgs = down ? st.in_msgs : st.out_msgs;
   const auto& recv_msgs = down ? st.out_msgs : st.in_msgs;
   if (send_msgs.empty() && recv_msgs.empty()) return;
-  if (nfields > xfields_) {
-    size_t most = 1;
-    for (const auto& s : plan_.steps) most = std::max(most, std::max(s.out_slots.size(), s.in_slots.size()));
-    sendbuf_.alloc_zero(most*nfields);
-    recvbuf_.alloc_zero(most*nfields);
-    xfields_ = nfields;
-  }
+  size_exchange_buffers(nfields);  // (a no-op after reserve_exchange)
   const int32_t* const send_dev = (down ? lvl_ins_.data() + lvl_off_[i].ins : lvl_outs_.data() + lvl_off_[i].outs);
   const int32_t* const recv_dev = (down ? lvl_outs_.data() + lvl_off_[i].outs : lvl_ins_.data() + lvl_off_[i].ins);
   if ( ! send_slots.empty())
     cedr_k_check(cedr_hip_gather_slots(data, stride_, nfields, send_dev, static_cast<int32_t>(send_slots.size()),
                                        sendbuf_.data(), stream));
-  std::vector<mpi::Comm::P2P> ops;
+  std::vector<mpi::Comm::P2P>& ops = ops_;
+  ops.clear();
   for (const auto& m : send_msgs)
     ops.push_back(mpi::Comm::P2P{m.peer, sendbuf_.data() + static_cast<size_t>(m.first)*nfields,
                                  static_cast<size_t>(m.count)*nfields, 1});

@@ -32,6 +32,9 @@ public:
   // (called from the owners' finish_setup). Needs a device.
   void upload();
   bool uploaded () const { return uploaded_; }
+  // Size the exchange buffers for sweeps of up to 'nfields' fields now (owners call it from
+  // finish_setup), so that no run() allocates or frees device memory.
+  void reserve_exchange(int32_t nfields);
 
   const plan::Plan& get_plan () const { return plan_; }
   // Doubles between consecutive fields: the plan's slot count rounded up to a
@@ -109,6 +112,7 @@ private:
   dev::Buffer<double> sendbuf_, recvbuf_, bcast_, bcast_send_;
   dev::Buffer<int32_t> root_slot_dev_;
   int32_t xfields_ = 0;
+  std::vector<mpi::Comm::P2P> ops_;  // scratch of level_exchange (reused: no allocation per round)
   bool uploaded_ = false;
   bool all_sums_ = false;
 };

@@ -87,14 +87,22 @@ struct RcclComm : public Comm {
   hipEvent_t done_ = nullptr;
   hipStream_t last_ = nullptr;
   bool used_ = false;
-  void order_before (hipStream_t s) {
-    if (used_ && s != last_) (void) hipStreamWaitEvent(s, done_, 0);
+  // Both return 0 or a HIP error: a collective whose ordering could not be set up must fail, not run
+  // concurrently with another one on the same communicator.
+  int order_before (hipStream_t s) {
+    if (used_ && s != last_) return static_cast<int>(hipStreamWaitEvent(s, done_, 0));
+    return 0;
   }
-  void order_after (hipStream_t s) {
-    if ( ! done_) (void) hipEventCreateWithFlags(&done_, hipEventDisableTiming);
-    (void) hipEventRecord(done_, s);
+  int order_after (hipStream_t s) {
+    if ( ! done_) {
+      const hipError_t e = hipEventCreateWithFlags(&done_, hipEventDisableTiming);
+      if (e != hipSuccess) { done_ = nullptr; return static_cast<int>(e); }
+    }
+    const hipError_t e = hipEventRecord(done_, s);
+    if (e != hipSuccess) return static_cast<int>(e);
     last_ = s;
     used_ = true;
+    return 0;
   }
   RcclComm (const void* id, int rank, int size) : comm_(nullptr), rank_(rank), size_(size) {
     const RcclApi& a = rccl();
@@ -111,30 +119,30 @@ struct RcclComm : public Comm {
   int rank () const override { return rank_; }
   int size () const override { return size_; }
   int allgather (const Real* send, Real* recv, size_t count, hipStream_t s) override {
-    order_before(s);
+    if (const int eo = order_before(s)) return eo;
     const int e = rccl().AllGather(send, recv, count, kNcclFloat64, comm_, s);
-    order_after(s);
-    return e;
+    const int ea = order_after(s);
+    return e != kNcclSuccess ? e : ea;
   }
   int allreduce_sum (const Real* send, Real* recv, size_t count, hipStream_t s) override {
-    order_before(s);
+    if (const int eo = order_before(s)) return eo;
     const int e = rccl().AllReduce(send, recv, count, kNcclFloat64, kNcclSum, comm_, s);
-    order_after(s);
-    return e;
+    const int ea = order_after(s);
+    return e != kNcclSuccess ? e : ea;
   }
   bool has_exchange () const override { return rccl().p2p; }
   int exchange (const P2P* ops, int nops, hipStream_t s) override {
     if (nops == 0) return 0;
     const RcclApi& a = rccl();
     if ( ! a.p2p) return -2;
-    order_before(s);
+    if (const int eo = order_before(s)) return eo;
     int e = a.GroupStart();
     for (int i = 0; i < nops && e == kNcclSuccess; ++i)
       e = ops[i].send ? a.Send(ops[i].buf, ops[i].count, kNcclFloat64, ops[i].peer, comm_, s)
                       : a.Recv(ops[i].buf, ops[i].count, kNcclFloat64, ops[i].peer, comm_, s);
     const int e2 = a.GroupEnd();
-    order_after(s);
-    return e != kNcclSuccess ? e : e2;
+    const int ea = order_after(s);
+    return e != kNcclSuccess ? e : (e2 != kNcclSuccess ? e2 : ea);
   }
 };
 

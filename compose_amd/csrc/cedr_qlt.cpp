@@ -215,6 +215,7 @@ void QLTHip::finish_setup () {
   Impl& d = *d_;
   if (o.l2r_data) return;  // already set up
   eng_->upload();
+  eng_->reserve_exchange(std::max(md_.prob2bl2r[MetaData::nprobtypes], md_.prob2br2l[MetaData::nprobtypes]));
   {  // tracer tables: caller order for the DeviceOp, bulk order for the kernels
     const Int nt = get_num_tracers();
     d.trcr2prob.upload(md_.trcr2prob);
