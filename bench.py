@@ -317,7 +317,10 @@ def main():
     # Default: QLT::run then CAAS::run on one stream. --overlap (N = 1): each CDR on its own stream.
     streams = None
     if a.overlap:
-        streams = (torch.cuda.Stream(device=device), torch.cuda.Stream(device=device))
+        # (experiment knob: CEDR_BENCH_PRIO="q,c" = HIP stream priorities of the QLT and the CAAS stream,
+        # lower number = higher priority, torch's range is -1..0)
+        pq, pc = [int(x) for x in os.environ.get("CEDR_BENCH_PRIO", "0,0").split(",")]
+        streams = (torch.cuda.Stream(device=device, priority=pq), torch.cuda.Stream(device=device, priority=pc))
         qlt.set_stream(streams[0].cuda_stream)
         caas.set_stream(streams[1].cuda_stream)
         for _, bfb in keep:

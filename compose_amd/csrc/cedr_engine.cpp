@@ -35,6 +35,28 @@ void DeviceStage::upload (const plan::Stage& st) {
   h.micro = st.micro.empty() ? nullptr : micro.data();
   outs.upload(st.outs);
   h.outs = outs.data();
+  h.flags = 0;
+  if ( ! st.micro.empty()) {
+    bool uni = true;
+    for (size_t i = 0; i < st.tiles.size(); ++i)
+      if (st.tiles[i].nleaf != 64 || st.tiles[i].micro_off != static_cast<int32_t>(64*i)) uni = false;
+    if (uni) h.flags |= CEDR_STAGE_UNIFORM64;
+  }
+  if (st.top && st.tiles.size() == 1) {
+    const plan::Tile& t = st.tiles[0];
+    const int32_t* const lp = st.lvlptr.data() + t.lvl_off;
+    const uint16_t* const kd = st.kids.data() + 2*static_cast<size_t>(t.kids_off);
+    if (t.nlvl > 0) {
+      const int32_t n0 = lp[1] - lp[0];
+      bool pairs = t.nleaf % 2 == 0 && 2*n0 == t.nleaf;
+      for (int32_t j = 0; pairs && j < n0; ++j) pairs = kd[2*j] == 2*j && kd[2*j + 1] == 2*j + 1;
+      if (pairs) h.flags |= CEDR_STAGE_LVL0_PAIRS;
+    }
+    int32_t narrow = t.nlvl;  // first level of the suffix of levels with <= 64 nodes each
+    while (narrow > 0 && lp[narrow] - lp[narrow - 1] <= 64) --narrow;
+    if (narrow < 1) narrow = 1;
+    if (narrow < 255) h.flags |= (narrow + 1) << 8;
+  }
 }
 
 TreeEngine::TreeEngine (const mpi::Parallel::Ptr& p, const tree::FlatTree& t,

@@ -387,6 +387,16 @@ __device__ __forceinline__ void store_cells (double* __restrict__ p, const int s
   if (size > 2) p[2] = c;
 }
 
+__device__ __forceinline__ Micro decode_micro (const uint32_t d, const bool valid) {
+  Micro m{0, -1, 0};
+  if (valid) {
+    m.start = d & 0xff;
+    m.shape = d >> 8;
+    m.size = m.shape == 0 ? 1 : (m.shape == 1 ? 2 : 3);
+  }
+  return m;
+}
+
 __device__ __forceinline__ Micro get_micro (const cedr_hip_stage& st, const cedr_hip_tile& tile,
                                             const int lane) {
   Micro m{0, -1, 0};
@@ -486,14 +496,17 @@ void tree_up_micro_kernel (const cedr_hip_stage st, const int nfields,
   extern __shared__ double lds[];
   const int tix = xcd_tile(st.ntiles);
   if (tix < 0) return;
-  const cedr_hip_tile tile = st.tiles[tix];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & (kWave - 1);
+  // (uniform stages: the micro-subtree descriptor does not wait for the tile descriptor)
+  const bool uni = (st.flags & CEDR_STAGE_UNIFORM64) != 0;
+  const uint32_t dpre = uni ? st.micro[64*static_cast<size_t>(tix) + lane] : 0;
+  const cedr_hip_tile tile = st.tiles[tix];
   uint32_t* const kidsL = reinterpret_cast<uint32_t*>(lds);
   int32_t* const lvlL = reinterpret_cast<int32_t*>(kidsL + st.max_nint);
   double* const v = lds + (st.max_nint + 1);
   const int nleaf = tile.nleaf;
   const int nchunks = (nfields + FT - 1)/FT;
-  const Micro m = get_micro(st, tile, lane);
+  const Micro m = uni ? decode_micro(dpre, true) : get_micro(st, tile, lane);
   // ROWS: a caller's row (nrow cells) has no padding behind its last cell, so a lane whose
   // 3-cell load window would reach past it reads the window cshift cells earlier and
   // picks its cells from the later window positions (fix_window).
@@ -1063,9 +1076,14 @@ void qlt_down_sp_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st,
   extern __shared__ double lds[];
   const int tix = xcd_tile(st.ntiles);
   if (tix < 0) return;
-  const cedr_hip_tile tile = st.tiles[tix];
   const int MN = st.max_nodes;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & (kWave - 1);
+  // (uniform stages could fetch the micro-subtree descriptor without waiting for the tile descriptor, as
+  // tree_up_micro_kernel does)
+  // (measured on this kernel: 6 more spilled VGPRs at its 96-register limit, 0.465 -> 0.527 ms -- not here)
+  const bool uni = false;
+  const uint32_t dpre = uni ? st.micro[64*static_cast<size_t>(tix) + lane] : 0;
+  const cedr_hip_tile tile = st.tiles[tix];
   uint32_t* const kidsL = reinterpret_cast<uint32_t*>(lds);
   int32_t* const lvlL = reinterpret_cast<int32_t*>(kidsL + st.max_nint);
   double* const rho = lds + (st.max_nint + 1);
@@ -1084,7 +1102,7 @@ void qlt_down_sp_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st,
   const bool prefer = L.prefer_mass_con != 0;
   const int nt = L.nt;
   const int nchunks = (nt + TT - 1)/TT;
-  const Micro m = get_micro(st, tile, lane);
+  const Micro m = uni ? decode_micro(dpre, true) : get_micro(st, tile, lane);
   const Roles ro = get_roles(m);
   const bool any2 = __ballot(m.shape == 2) != 0, any3 = __ballot(m.shape == 3) != 0;
   const int ushift = (ROWS && tile.in0 + ro.oUV + 1 > nrow - 1) ? 1 : 0;
@@ -1190,8 +1208,10 @@ void qlt_down_sp_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st,
           const double* K0 = Rw + 4*(kk & 0xffff);
           const double* K1 = Rw + 4*(kk >> 16);
           double* me = Rw + 4*(nleaf + j);
-          me[0] = K0[0] + K1[0]; me[2] = K0[2] + K1[2];
-          me[1] = K0[1] + K1[1];
+          // (all six reads before the first write: the compiler must assume me aliases K0 / K1 and would
+          // otherwise wait for LDS three times)
+          const double a0 = K0[0], a1 = K0[1], a2 = K0[2], b0 = K1[0], b1 = K1[1], b2 = K1[2];
+          me[0] = a0 + b0; me[1] = a1 + b1; me[2] = a2 + b2;
         }
       }
     }
@@ -1500,6 +1520,13 @@ __device__ unsigned long long g_top_stamps[64];
 # define TSTAMP(i)
 #endif
 
+// First level of the narrow suffix of a top tile's levels (every level from there up has <= 64 nodes),
+// at least 1; the host passes it + 1 in bits 8..15 of the stage's flags (0 = not given: no narrow levels).
+__device__ __forceinline__ int top_narrow_from (const cedr_hip_stage& st, const cedr_hip_tile& tile) {
+  const int v = (st.flags >> 8) & 0xff;
+  return v ? min(max(v - 1, 1), tile.nlvl) : tile.nlvl;
+}
+
 struct TopMeta {
   uint32_t* kidsL;
   int32_t* lvlL;
@@ -1544,16 +1571,17 @@ void tree_top_up_kernel (const cedr_hip_stage st, const cedr_hip_tile tile, cons
   // table has been staged in LDS
   const uint32_t* __restrict__ const kp = reinterpret_cast<const uint32_t*>(st.kids + 2*static_cast<size_t>(tile.kids_off));
   // (n0 is only needed once the loads are under way: nodes past level 0 among the first 1024 just
-  // load an input for nothing)
-  const int n0 = tile.nlvl > 0 ? st.lvlptr[tile.lvl_off + 1] : 0;
+  // load an input for nothing). With CEDR_STAGE_LVL0_PAIRS node j's kids are known: inputs 2j, 2j + 1.
+  const bool pairs = (st.flags & CEDR_STAGE_LVL0_PAIRS) != 0;
+  const int n0 = pairs ? nleaf/2 : (tile.nlvl > 0 ? st.lvlptr[tile.lvl_off + 1] : 0);
   constexpr int NB0 = 1024*FPB/kTopBlock;  // items of level 0 per thread
   double k0[NB0], k1[NB0];
   {
     uint32_t kk[NB0];
 #pragma unroll
     for (int u = 0; u < NB0; ++u) {
-      const int q = threadIdx.x + u*kTopBlock;
-      kk[u] = (q >> LF) < tile.nint ? kp[q >> LF] : 0;
+      const int j = (threadIdx.x + u*kTopBlock) >> LF;
+      kk[u] = pairs ? (2*j + 1 < nleaf ? (2*j) | ((2*j + 1) << 16) : 0) : (j < tile.nint ? kp[j] : 0);
     }
 #pragma unroll
     for (int u = 0; u < NB0; ++u) {
@@ -1567,6 +1595,7 @@ void tree_top_up_kernel (const cedr_hip_stage st, const cedr_hip_tile tile, cons
   const int o = live ? op[f] : 0;
   double* const vf = v + ff*pitch;
   auto val = [&] (const int c) -> double { return c < nleaf ? row[c] : vf[c - nleaf]; };
+  const int narrow = top_narrow_from(st, tile);
   TSTAMP(32);
 #pragma unroll
   for (int u = 0; u < NB0; ++u) {
@@ -1575,7 +1604,7 @@ void tree_top_up_kernel (const cedr_hip_stage st, const cedr_hip_tile tile, cons
   }
   __syncthreads();
   TSTAMP(33);
-  for (int lv = 1; lv < tile.nlvl; ++lv) {
+  for (int lv = 1; lv < narrow; ++lv) {
     const int a = M.lvlL[lv];
     const int nitems = (M.lvlL[lv+1] - a) << LF;
     for (int q0 = threadIdx.x; q0 < nitems; q0 += 2*kTopBlock) {
@@ -1598,6 +1627,28 @@ void tree_top_up_kernel (const cedr_hip_stage st, const cedr_hip_tile tile, cons
     }
     __syncthreads();
   }
+  // Narrow levels (<= 64 nodes each): wave w takes field w of the workgroup's FPB, lane = node, level
+  // after level in program order -- no workgroup barrier.
+  {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & (kWave - 1);
+    const int fw = blockIdx.x*FPB + wave;
+    if (wave < FPB && fw < nfields) {
+      const int ow = op[fw];
+      const double* __restrict__ const roww = data + static_cast<size_t>(fw)*stride + tile.in0;
+      double* const vw = v + wave*pitch;
+      for (int lv = narrow; lv < tile.nlvl; ++lv) {
+        const int a = M.lvlL[lv], n = M.lvlL[lv+1] - a;
+        if (lane < n) {
+          const uint32_t kk = M.kidsL[a + lane];
+          const int c0 = kk & 0xffff, c1 = kk >> 16;
+          vw[a + lane] = combine(ow, zero_init, c0 < nleaf ? roww[c0] : vw[c0 - nleaf],
+                                 c1 < nleaf ? roww[c1] : vw[c1 - nleaf]);
+        }
+        wave_lds_order();
+      }
+    }
+  }
+  __syncthreads();
   TSTAMP(34);
   if ( ! live) return;
   for (int k = threadIdx.x >> LF; k < tile.nout; k += kTopBlock/FPB)
@@ -1651,7 +1702,7 @@ void qlt_top_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st, const
   const bool t_only = (pt & CONSISTENT) && ! sp;
   const bool cons = (pt & CONSERVE) != 0;
   const int in0 = tile.in0;
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & (kWave - 1);
   // l2r field of record entry k (-1: the tracer has none), as in qlt_apex_kernel
   auto field_of = [&] (const int k) -> int {
     if (pt & NONNEGATIVE) return k == 1 ? lb : ((k == 3 && cons) ? lb + 1 : -1);
@@ -1659,18 +1710,27 @@ void qlt_top_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st, const
   };
   auto rule_of = [&] (const int k) -> int { return (t_only && k == 0) ? 1 : ((t_only && k == 2) ? 2 : 0); };
   const double* __restrict__ const rrow = l2r + in0;
+  // NARROW levels: the levels from 'narrow' up have at most 64 nodes each (host-computed, >= 1). One wave
+  // walks them alone -- per quantity on the way up (waves 0-3: record entry = wave; wave 4: densities),
+  // wave 0 on the way down -- in program order, with no workgroup barrier between them.
+  const int narrow = top_narrow_from(st, tile);
   TSTAMP(0);
 
-  // ---- level 0 in registers: kid indices straight from global memory, then every load at once.
-  // (n0 is only needed once the loads are under way: a node past level 0 just loads an input for nothing)
+  // ---- level 0 in registers: kid indices straight from global memory (or known: inputs 2j, 2j + 1),
+  // then every load at once. (n0 is only needed once the loads are under way: a node past level 0 just
+  // loads an input for nothing)
   const uint32_t* __restrict__ const kp = reinterpret_cast<const uint32_t*>(st.kids + 2*static_cast<size_t>(tile.kids_off));
-  const int n0 = tile.nlvl > 0 ? st.lvlptr[tile.lvl_off + 1] : 0;
+  const bool pairs = (st.flags & CEDR_STAGE_LVL0_PAIRS) != 0;
+  const int n0 = pairs ? nleaf/2 : (tile.nlvl > 0 ? st.lvlptr[tile.lvl_off + 1] : 0);
   int c0r[2];               // this thread's level-0 node: its kids' input indices
   double f0[2][4], r0[2];   // their records and densities
   {
-    const uint32_t kk = tid < nint ? kp[tid] : 0;
-    const int a = kk & 0xffff, b = kk >> 16;
-    c0r[0] = a < nleaf ? a : 0; c0r[1] = b < nleaf ? b : 0;
+    if (pairs) { c0r[0] = 2*tid < nleaf ? 2*tid : 0; c0r[1] = 2*tid + 1 < nleaf ? 2*tid + 1 : 0; }
+    else {
+      const uint32_t kk = tid < nint ? kp[tid] : 0;
+      const int a = kk & 0xffff, b = kk >> 16;
+      c0r[0] = a < nleaf ? a : 0; c0r[1] = b < nleaf ? b : 0;
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int fk = field_of(k);
@@ -1683,18 +1743,16 @@ void qlt_top_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st, const
     for (int e = 0; e < 2; ++e) r0[e] = rrow[c0r[e]];
   }
   // Mode 2: everything the apex part will need from global memory is requested now as well -- the
-  // gathered records (through src), this thread's boundary root and where it goes -- so that it arrives
-  // while the tile's sums are formed. One item per thread: an apex tile has <= 64 inputs.
+  // gathered records (through src; wave w < 4 takes entry w of every apex input, wave 4 its density), this
+  // thread's boundary root and where it goes -- so that it arrives while the tile's sums are formed.
   const int an = A.tile.nleaf, nf = L.l2rndps;
-  double av = 0, avr = 0;
+  double av = 0;
   int my_in_r = 0, my_slot_r = -1, my_node_r = -1;
   const int root_node = mode == 1 ? st.outs[tile.outs_off] : 0;
   if (mode == 2) {
-    if (tid < 4*an) {
-      const int fk = field_of(tid & 3);
-      const size_t rec = static_cast<size_t>(A.src[tid >> 2])*nf;
-      av = fk >= 0 ? A.recv[rec + fk] : 0.0;
-      if ((tid & 3) == 0) avr = A.recv[rec];
+    if (wave < 5 && lane < an) {
+      const int fk = wave < 4 ? field_of(wave) : 0;
+      av = fk >= 0 ? A.recv[static_cast<size_t>(A.src[lane])*nf + fk] : 0.0;
     }
     if (tid < A.nmine) {
       my_in_r = A.my_in[tid];
@@ -1733,15 +1791,16 @@ void qlt_top_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st, const
   __syncthreads();
   TSTAMP(1);
 
-  // ---- sums of the other internal nodes, level by level: entries 0..2 (and 3 = Qm_prev when the
-  // root is computed here) of every node's record, and its density. A kid may still be an input.
+  // ---- sums of the other internal nodes: entries 0..2 (and 3 = Qm_prev when the root is computed
+  // here) of every node's record, and its density. A kid may still be an input.
+  // Wide levels: (node, entry) items over all threads, a barrier per level.
   {
     const int k = tid & 3;
     const int fk = field_of(k);
     const bool want = fk >= 0 && (k < 3 || mode == 1);
     const double* __restrict__ const frow = l2r + static_cast<size_t>(fk < 0 ? 0 : fk)*S + in0;
     const int ok = rule_of(k);
-    for (int lv = 1; lv < tile.nlvl; ++lv) {
+    for (int lv = 1; lv < narrow; ++lv) {
       const int a = M.lvlL[lv], n = M.lvlL[lv+1] - a;
       for (int q = tid; q < 4*n; q += kTopBlock) {
         double r = 0.0;
@@ -1760,14 +1819,60 @@ void qlt_top_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st, const
       }
       __syncthreads();
     }
-    for (int j = tid; j < nint; j += kTopBlock) {
-      const double w = 1.0/rho[j];
-      rw[j] = w;
-      rq[j] = 1.0/w;
+  }
+  // Narrow levels (and, mode 2, the apex tile leaves->root, all of whose levels are narrow): one wave
+  // per quantity, lane = node.
+  if (wave < 5) {
+    const int k = wave;  // 0..3: record entry; 4: density
+    const int fk = k < 4 ? field_of(k) : 0;
+    const bool want = k == 4 || (fk >= 0 && (k < 3 || mode == 1));
+    const bool awant = k == 4 || fk >= 0;  // the apex sums include Qm_prev: its root is computed here
+    const double* __restrict__ const frow = l2r + static_cast<size_t>(fk < 0 ? 0 : fk)*S + in0;
+    const int ok = k < 4 ? rule_of(k) : 0;
+    for (int lv = narrow; lv < tile.nlvl; ++lv) {
+      const int a = M.lvlL[lv], n = M.lvlL[lv+1] - a;
+      if (lane < n) {
+        const int j = a + lane;
+        double r = 0.0;
+        if (want) {
+          const uint32_t kk = M.kidsL[j];
+          const int c0 = kk & 0xffff, c1 = kk >> 16;
+          if (k < 4) r = combine(ok, 0, c0 < nleaf ? frow[c0] : recs[4*(c0 - nleaf) + k],
+                                 c1 < nleaf ? frow[c1] : recs[4*(c1 - nleaf) + k]);
+          else r = (c0 < nleaf ? rrow[c0] : rho[c0 - nleaf]) + (c1 < nleaf ? rrow[c1] : rho[c1 - nleaf]);
+        }
+        if (k < 4) recs[4*j + k] = r;
+        else { rho[j] = r; const double w = 1.0/r; rw[j] = w; rq[j] = 1.0/w; }
+      }
+      wave_lds_order();
+    }
+    if (mode == 2) {
+      if (lane < an) {
+        if (k < 4) arec[4*lane + k] = av;
+        else { arho[lane] = av; const double w = 1.0/av; arw[lane] = w; arq[lane] = 1.0/w; }
+      }
+      wave_lds_order();
+      for (int lv = 0; lv < A.tile.nlvl; ++lv) {
+        const int a = alvl[lv], n = alvl[lv+1] - a;
+        if (lane < n) {
+          const uint32_t kk = akids[a + lane];
+          const int c0 = kk & 0xffff, c1 = kk >> 16, me = an + a + lane;
+          if (k < 4) arec[4*me + k] = awant ? combine(ok, 0, arec[4*c0 + k], arec[4*c1 + k]) : 0.0;
+          else { const double r = arho[c0] + arho[c1]; arho[me] = r; const double w = 1.0/r; arw[me] = w; arq[me] = 1.0/w; }
+        }
+        wave_lds_order();
+      }
     }
   }
-
+  // reciprocals of the wide levels' densities (the narrow ones have theirs)
+  for (int j = tid; j < M.lvlL[narrow]; j += kTopBlock) {
+    const double w = 1.0/rho[j];
+    rw[j] = w;
+    rq[j] = 1.0/w;
+  }
+  __syncthreads();
   TSTAMP(2);
+
   // ---- assigned masses of the tile's outputs; the global q bounds of a consistent-only tracer
   double qlo = 0, qhi = 0;
   // an output that is an input of the tile (a subtree root the previous stage finished): pass on
@@ -1800,46 +1905,30 @@ void qlt_top_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st, const
       if (tid == 0) put_input(node, l2r[fo*S + in0 + node], qlo, qhi);
     }
   } else {
-    // apex, leaves->root: this tracer's records of all ranks' boundary roots, then root_compute
-    const cedr_hip_tile at = A.tile;
-    if (tid < 4*an) {
-      arec[tid] = av;
-      if ((tid & 3) == 0) arho[tid >> 2] = avr;
-    }
-    __syncthreads();
-    for (int lv = 0; lv < at.nlvl; ++lv) {
-      const int a = alvl[lv], n = alvl[lv+1] - a;
-      for (int q = tid; q < 5*n; q += kTopBlock) {
-        const uint32_t kk = akids[a + q/5];
-        const int k = q % 5, c0 = kk & 0xffff, c1 = kk >> 16, me = an + a + q/5;
-        if (k == 4) arho[me] = arho[c0] + arho[c1];
-        else arec[4*me + k] = combine(rule_of(k), 0, arec[4*c0 + k], arec[4*c1 + k]);
-      }
-      __syncthreads();
-    }
-    for (int i = tid; i < an + at.nint; i += kTopBlock) {
-      const double w = 1.0/arho[i];
-      arw[i] = w;
-      arq[i] = 1.0/w;
-    }
     if (t_only) { qlo = arec[4*aroot]; qhi = arec[4*aroot + 2]; }
-    __syncthreads();
     if (tid == 0 && ! cons) arec[4*aroot + 3] = arec[4*aroot + 1];
   }
+  __syncthreads();
 
   // ---- node problems: the apex tile's levels from its root down (mode 2), the hand-over of this
   // rank's boundary roots, then the top tile's levels from its outputs down. One node per thread and
   // level. What a node problem needs of an INPUT kid of the top tile comes from global memory (level 0:
-  // from the registers) and does not depend on the level above: it is requested before the barrier that
-  // publishes that level's results, so its latency overlaps the wait.
+  // from the registers) and does not depend on the level above: it is requested before the results of
+  // that level are waited for. Everything else it needs but its own assigned mass -- the kids' sums and
+  // densities in LDS -- is read before that point, too. The steps over narrow levels are wave 0's alone,
+  // in program order; the wide ones are separated by workgroup barriers.
   const int fo = sp ? lb + 1 : ((pt & CONSISTENT) ? lb + 1 : lb);  // the 'orig' field
   const double* __restrict__ const orow = l2r + static_cast<size_t>(fo)*S + in0;
   const double* __restrict__ const lrow = l2r + static_cast<size_t>(lb)*S + in0;        // lo (sp)
   const double* __restrict__ const hrow = l2r + static_cast<size_t>(lb + 2)*S + in0;    // hi (sp)
   const int asteps = mode == 2 ? A.tile.nlvl : 0;
+  const int nsteps = asteps + tile.nlvl;
+  const int nnarrow = asteps + (tile.nlvl - narrow);  // the first steps: narrow
   TSTAMP(3);
-  for (int s = 0; s < asteps + tile.nlvl; ++s) {
+  for (int s = 0; s < nsteps; ++s) {
     if (s < 24) TSTAMP(4 + s);
+    const bool narrow_step = s < nnarrow;
+    if (narrow_step && wave != 0) continue;
     const bool ap = s < asteps;
     const int lv = ap ? asteps - 1 - s : tile.nlvl - 1 - (s - asteps);
     const uint32_t* const KD = ap ? akids : M.kidsL;
@@ -1855,8 +1944,8 @@ void qlt_top_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st, const
     const bool regs = ! ap && lv == 0;   // the top tile's lowest level: kids in this thread's registers
     if (mode == 2 && s == asteps) {
       // this rank's boundary roots: to their r2l slots (roots an earlier stage finished are read from
-      // there by that stage) and, for this tile's outputs, into the tile
-      __syncthreads();
+      // there by that stage) and, for this tile's outputs, into the tile. (<= 64 of them: wave 0's lanes.)
+      if (narrow_step) wave_lds_order(); else __syncthreads();
       if (tid < A.nmine) {
         const double x = arec[4*my_in_r + 3];
         r2l[rb*S + my_slot_r] = x;
@@ -1884,9 +1973,6 @@ void qlt_top_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st, const
           if (sp) { klo[e] = lrow[cc[e]]; khi[e] = hrow[cc[e]]; }
         }
     }
-    // Everything but the node's own assigned mass is independent of the level above -- the kids' sums
-    // and densities in LDS as well: read before the barrier, so that only one LDS read and the node
-    // problem itself follow it.
     KidRho kr[2];
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
@@ -1902,7 +1988,8 @@ void qlt_top_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st, const
     const int me = pb + a + (act ? tid : 0);
     const double* const P = RC + 4*me;
     const double plo = P[0], por = P[1], phi = P[2], prh = RH[me];
-    __syncthreads();
+    // the results of the level above: wave 0's own (narrow steps), or everybody's
+    if (narrow_step) wave_lds_order(); else __syncthreads();
     if ( ! act) continue;
     double xs[2];
     solve_node(pt, prh, t_only ? qlo : plo, por, t_only ? qhi : phi, P[3],

@@ -190,6 +190,19 @@ __host__ __device__ inline void node_problem_mass (const double p_lo, const doub
   qp_2d(r0.w, r1.w, r0.q, r1.q, Qm, lo0, lo1, hi0, hi1, or0, or1, x0, x1, ! prefer, ! prefer);
 }
 
+// The branchy routine as the wave-oriented form below calls it (rarely). Inlined by default.
+#ifdef CEDR_NP_COLD_NOINLINE  // (measured: a real call costs 29 spilled VGPRs around it in the kernel)
+__host__ __device__ __attribute__((noinline))
+#else
+__host__ __device__ inline
+#endif
+void node_problem_mass_cold (const double p_lo, const double p_orig, const double p_hi, const double Qm,
+                             const KidRho r0, const double lo0, const double or0, const double hi0,
+                             const KidRho r1, const double lo1, const double or1, const double hi1,
+                             double& x0, double& x1, const bool prefer) {
+  node_problem_mass(p_lo, p_orig, p_hi, Qm, r0, lo0, or0, hi0, r1, lo1, or1, hi1, x0, x1, prefer);
+}
+
 // The same node problem (bit-identical results) written for how a wave executes it. The lanes of a
 // wave almost never agree on which way node_problem_mass branches, so the wave runs both sides of
 // nearly every `if`, and every divergent branch costs a saveexec / branch / restore sequence and a
@@ -290,7 +303,7 @@ void node_problem_mass_wave (const double p_lo, const double p_orig, const doubl
   }
   if (CEDR_WAVE_ANY(general)) {
     CEDR_NP_TRACE(0);
-    node_problem_mass(p_lo, p_orig, p_hi, Qm, r0, lo0, or0, hi0, r1, lo1, or1, hi1, x0, x1, prefer);
+    node_problem_mass_cold(p_lo, p_orig, p_hi, Qm, r0, lo0, or0, hi0, r1, lo1, or1, hi1, x0, x1, prefer);
     return;
   }
   CEDR_NP_TRACE(quick ? 1 : (exl || exh ? 2 : (inside ? 3 : 4)));
@@ -385,14 +398,14 @@ void node_problems_mass (const double (&p_lo)[N], const double (&p_orig)[N], con
 }
 
 // reference cedr_qlt_inl.hpp:175-203 (dispatch on problem type)
-__device__ void solve_node (const int pt, const double rh, const double p_lo,
+__host__ __device__ inline void solve_node (const int pt, const double rh, const double p_lo,
                             const double p_orig, const double p_hi, const double Qm,
                             const KidRho r0, const double lo0, const double or0, const double hi0,
                             const KidRho r1, const double lo1, const double or1, const double hi1,
                             double& x0, double& x1, const bool prefer) {
   if ((pt & CONSISTENT) && ! (pt & SHAPEPRESERVE)) {
-    node_problem_mass(p_lo*rh, p_orig, p_hi*rh, Qm,
-                      r0, lo0*r0.rh, or0, hi0*r0.rh, r1, lo1*r1.rh, or1, hi1*r1.rh, x0, x1, prefer);
+    node_problem_mass_wave(p_lo*rh, p_orig, p_hi*rh, Qm,
+                           r0, lo0*r0.rh, or0, hi0*r0.rh, r1, lo1*r1.rh, or1, hi1*r1.rh, x0, x1, prefer);
   } else if (pt & NONNEGATIVE) {
     // solve_1eq_nonneg(2, ones, Qm, y, x, w, least_squares), cedr_local_inl.hpp:309-330
     x0 = or0;
@@ -400,8 +413,8 @@ __device__ void solve_node (const int pt, const double rh, const double p_lo,
     if (Qm < 0) return;
     qp_2d(r0.w, r1.w, r0.q, r1.q, Qm, 0.0, 0.0, Qm, Qm, or0, or1, x0, x1, true, true);
   } else {
-    node_problem_mass(p_lo, p_orig, p_hi, Qm, r0, lo0, or0, hi0, r1, lo1, or1, hi1,
-                      x0, x1, prefer);
+    node_problem_mass_wave(p_lo, p_orig, p_hi, Qm, r0, lo0, or0, hi0, r1, lo1, or1, hi1,
+                           x0, x1, prefer);
   }
 }
 

@@ -53,7 +53,16 @@ typedef struct {
   const int32_t* lvlptr;
   const uint16_t* micro;
   const uint16_t* outs;
+  int32_t flags;  /* CEDR_STAGE_*: properties of the whole stage that let kernels skip a dependent load */
 } cedr_hip_stage;
+/* micro stage whose every tile has exactly 64 micro-subtrees: tile t's descriptors are micro[64*t ...], so a
+ * workgroup can fetch them without waiting for its tile descriptor */
+enum { CEDR_STAGE_UNIFORM64 = 1,
+/* fused top tile: the first level's node j has the inputs 2j and 2j + 1 as its kids and there are nleaf/2 of
+ * them, so its loads need not wait for the kid table */
+       CEDR_STAGE_LVL0_PAIRS = 2 };
+/* fused top tile, bits 8..15 of flags: 1 + the first level of the NARROW suffix of the tile's levels (every
+ * level from there up has at most 64 nodes; one wave walks those without workgroup barriers); 0 = not given */
 
 /* QLT record layout. Bulk data are stored field-major:
  *   l2r[field*stride + slot], r2l[field*stride + slot]
