@@ -2123,7 +2123,21 @@ __global__ void qlt_get_Qm_kernel (const int32_t* __restrict__ trcr_r2l, const i
 }
 
 // ------------------------------------------------------------------- CAAS
-constexpr int kCaasChunk = 4096;  // cells per workgroup
+// Cells per workgroup. Round 3: SMALL chunks -- 512 cells = ONE 16-byte load per array and thread, no loop -- beat
+// long ones: the streams are kept in flight by the number of resident workgroups, not by a loop's iterations
+// (reduce 0.416 -> 0.385 ms, finish 0.253 -> 0.222 ms at 1.5M cells x 40 tracers; 256 cells per workgroup
+// leave half the threads idle: reduce 0.51 ms; 1024-16384: monotonically slower).
+#ifndef CEDR_CAAS_CHUNK
+# define CEDR_CAAS_CHUNK 512
+#endif
+#ifndef CEDR_CAAS_UNROLL
+# define CEDR_CAAS_UNROLL 1
+#endif
+constexpr int kCaasChunk = CEDR_CAAS_CHUNK;  // cells per workgroup, reduce pass (one partial sum each)
+#ifndef CEDR_CAAS_FINISH_CHUNK
+# define CEDR_CAAS_FINISH_CHUNK CEDR_CAAS_CHUNK
+#endif
+constexpr int kCaasFinishChunk = CEDR_CAAS_FINISH_CHUNK;  // ... finish pass
 
 // CAAS streams every array exactly once per pass and nothing is re-read before
 // ~2 GB of other data has gone by, so its accesses are non-temporal: +12 % on
@@ -2185,6 +2199,7 @@ void caas_reduce_kernel (const int32_t* __restrict__ probs, const int nt, const 
     const d2* __restrict__ vhi = reinterpret_cast<const d2*>(qhi);
     const d2* __restrict__ vpv = reinterpret_cast<const d2*>(qpv);
     d2* __restrict__ vout = reinterpret_cast<d2*>(qm);
+#pragma unroll CEDR_CAAS_UNROLL
     for (int i = beg/2 + threadIdx.x; i < end/2; i += kBlock) {
 #if CEDR_CAAS_NT
       const d2 q = __builtin_nontemporal_load(vin + i), lo = __builtin_nontemporal_load(vlo + i),
@@ -2225,15 +2240,19 @@ void caas_reduce_kernel (const int32_t* __restrict__ probs, const int nt, const 
   }
 }
 
-// One wave per (sum kind, tracer): add the chunk partials in a fixed order.
-__global__ __launch_bounds__(kWave)
+// One workgroup per (sum kind, tracer): add the chunk partials in a fixed order -- thread t takes partials
+// t, t + 256, ... (independent loads, all in flight), then lanes by shuffle and the four waves in order.
+__global__ __launch_bounds__(kBlock)
 void caas_sum_partials_kernel (const int nchunks, const double* __restrict__ partials,
                                double* __restrict__ send) {
+  __shared__ double sm[kNW];
   const double* __restrict__ p = partials + static_cast<size_t>(blockIdx.x)*nchunks;
   double v = 0;
-  for (int c = threadIdx.x; c < nchunks; c += kWave) v += p[c];
+  for (int c = threadIdx.x; c < nchunks; c += kBlock) v += p[c];
   v = wave_sum(v);
-  if (threadIdx.x == 0) send[blockIdx.x] = v;
+  if ((threadIdx.x & (kWave - 1)) == 0) sm[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) send[blockIdx.x] = ((sm[0] + sm[1]) + sm[2]) + sm[3];
 }
 
 // reference cedr_caas.cpp:140-168 (user-reducer branch): thread per (field, group).
@@ -2278,7 +2297,10 @@ __global__ void caas_reduce_accum_kernel (const int32_t* __restrict__ probs, con
 // are bit-identical. LDS rows are padded by one double per group, which keeps the
 // group-strided reads of the second phase off a single bank.
 constexpr int kAccumSub = 1024;  // cells per sub-block (upper bound; a multiple of n_accum is used)
-constexpr int kAccumNsb = 4;     // sub-blocks per workgroup
+#ifndef CEDR_CAAS_ACCUM_NSB
+# define CEDR_CAAS_ACCUM_NSB 4
+#endif
+constexpr int kAccumNsb = CEDR_CAAS_ACCUM_NSB;     // sub-blocks per workgroup
 __global__ __launch_bounds__(kBlock)
 void caas_reduce_accum_lds_kernel (const int32_t* __restrict__ probs, const int nt, const int n,
                                    const int need_conserve, const int na, const int sb,
@@ -2349,11 +2371,12 @@ void caas_finish_kernel (const int nt, const int n, double* __restrict__ qm_io,
   const size_t N = n;
   double* __restrict__ qm = qm_io + k*N;
   const double* __restrict__ bnd = (toward_max ? qm_max : qm_min) + k*N;
-  const int beg = c*kCaasChunk, end = min(n, beg + kCaasChunk);
+  const int beg = c*kCaasFinishChunk, end = min(n, beg + kCaasFinishChunk);
   if (VEC == 2) {
     typedef double __attribute__((ext_vector_type(2))) d2;
     d2* __restrict__ vq = reinterpret_cast<d2*>(qm);
     const d2* __restrict__ vb = reinterpret_cast<const d2*>(bnd);
+#pragma unroll CEDR_CAAS_UNROLL
     for (int i = beg/2 + threadIdx.x; i < end/2; i += kBlock) {
 #if CEDR_CAAS_NT
       d2 q = __builtin_nontemporal_load(vq + i);
@@ -2906,7 +2929,7 @@ int cedr_hip_caas_reduce_local (const int32_t* probs, int32_t nt, int32_t n, int
 int cedr_hip_caas_sum_partials (int32_t nt, int32_t n, const double* partials, double* send,
                                 cedr_stream_t stream) {
   ProfScope ps(K_CAAS_SUM, n, stream);
-  hipLaunchKernelGGL(caas_sum_partials_kernel, dim3(4*nt), dim3(kWave), 0, stream,
+  hipLaunchKernelGGL(caas_sum_partials_kernel, dim3(4*nt), dim3(kBlock), 0, stream,
                      cedr_hip_caas_nchunks(n), partials, send);
   return launch_status();
 }
@@ -2934,7 +2957,7 @@ int cedr_hip_caas_finish_local_arrays (int32_t nt, int32_t n, double* qm, const 
                                        const double* qm_max, const double* recv,
                                        cedr_stream_t stream) {
   ProfScope ps(K_CAAS_FINISH, n, stream);
-  const dim3 grid(cedr_hip_caas_nchunks(n), nt);
+  const dim3 grid((n + kCaasFinishChunk - 1)/kCaasFinishChunk, nt);
   const bool vec = n % 2 == 0 && reinterpret_cast<uintptr_t>(qm) % 16 == 0 &&
     reinterpret_cast<uintptr_t>(qm_min) % 16 == 0 && reinterpret_cast<uintptr_t>(qm_max) % 16 == 0;
   if (vec)
