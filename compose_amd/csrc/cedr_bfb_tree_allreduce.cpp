@@ -81,6 +81,7 @@ void BfbTreeAllReducerHip::finish_setup () {
   for (Int i = 0; i < nlocal_; ++i) if (ls[i] != i) m_->identity = false;
   m_->root_slot.upload(std::vector<int32_t>(1, eng_->get_plan().root_slot));
   m_->op.upload(std::vector<uint8_t>(nfield_, 0));
+  eng_->set_all_sums(true);  // every field is a sum (0 + kid0 + kid1: the zero-init flavour of the sum kernels)
 }
 
 void BfbTreeAllReducerHip::allreduce (const Real* send, Real* recv, const bool transpose) const {

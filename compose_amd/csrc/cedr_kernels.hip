@@ -473,6 +473,15 @@ __device__ __forceinline__ double micro_up_sum (const int shape, const double a,
   return shape <= 0 ? a : (shape == 1 ? t : r);
 }
 
+// The same when every node is 0 + kid0 + kid1 (BfbTreeAllReducer, cedr_bfb_tree_allreduce.cpp:117-123): the leading
+// zero stays -- 0 + (-0) is +0, so dropping it would change the sign of a zero.
+__device__ __forceinline__ double micro_up_sum_zi (const int shape, const double a, const double b,
+                                                   const double c) {
+  const double t = (0.0 + (shape == 3 ? b : a)) + (shape == 3 ? c : b);
+  const double r = (0.0 + (shape == 2 ? t : a)) + (shape == 2 ? c : t);
+  return shape <= 0 ? a : (shape == 1 ? t : r);
+}
+
 // ROWS: the tile's INPUT rows come from a table of per-field base pointers
 // (in_rows[f] + slot) instead of data + f*stride + slot -- the caller's own
 // [tracer][cell] arrays in zero-copy mode. Outputs always go to 'data'.
@@ -483,9 +492,10 @@ __device__ double* g_diag_blk;
 #if ! defined(__OPTIMIZE__) && ! defined(CEDR_UP_NOPREFETCH)
 # define CEDR_UP_NOPREFETCH
 #endif
+// ZI (with SUMS): every node is 0 + kid0 + kid1 instead (the BFB reducer's sums).
 // SUMS: the caller guarantees that every field's rule is a plain sum and zero_init is 0 (QLT without
 // consistent-only tracers -- E3SM's case): no rule table, no per-field branches in the chunk loop.
-template <int FT, bool ROWS, bool SUMS>
+template <int FT, bool ROWS, bool SUMS, bool ZI = false>
 __global__ __launch_bounds__(kBlock)
 void tree_up_micro_kernel (const cedr_hip_stage st, const int nfields,
                            const uint8_t* __restrict__ op, const int64_t stride,
@@ -590,8 +600,9 @@ void tree_up_micro_kernel (const cedr_hip_stage st, const int nfields,
         wa = cshift == 0 ? wa : (cshift == 1 ? wb : wc);
         wb = cshift == 0 ? wb : wc;
       }
-      const double val = (SUMS || (orow == 0 && ! zero_init)) ?
-        micro_up_sum(m.shape, wa, wb, wc) : micro_up(m.shape, orow, zero_init, wa, wb, wc);
+      const double val = (SUMS && ZI) ? micro_up_sum_zi(m.shape, wa, wb, wc) :
+        ((SUMS || (orow == 0 && ! zero_init)) ?
+         micro_up_sum(m.shape, wa, wb, wc) : micro_up(m.shape, orow, zero_init, wa, wb, wc));
       if (lane < nleaf) v[(wave + kNW*r)*pitch + lane] = val;
     }
     STAMP(1);  // issue prefetch + micro combines
@@ -615,7 +626,8 @@ void tree_up_micro_kernel (const cedr_hip_stage st, const int nfields,
       for (int q = lane; q < nitems; q += kWave) {
         const int j = a + (q >> LR);
         const uint32_t kk = kidsL[j];
-        if (SUMS) vr[nleaf + j] = vr[kk & 0xffff] + vr[kk >> 16];
+        if (SUMS && ZI) vr[nleaf + j] = (0.0 + vr[kk & 0xffff]) + vr[kk >> 16];
+        else if (SUMS) vr[nleaf + j] = vr[kk & 0xffff] + vr[kk >> 16];
         else vr[nleaf + j] = combine(o, zero_init, vr[kk & 0xffff], vr[kk >> 16]);
       }
     }
@@ -2301,6 +2313,7 @@ constexpr int kAccumSub = 1024;  // cells per sub-block (upper bound; a multiple
 # define CEDR_CAAS_ACCUM_NSB 4
 #endif
 constexpr int kAccumNsb = CEDR_CAAS_ACCUM_NSB;     // sub-blocks per workgroup
+template <int VEC>  // 2: 16-byte accesses, two cells per thread and pass (needs n and sb even, 16-byte aligned rows)
 __global__ __launch_bounds__(kBlock)
 void caas_reduce_accum_lds_kernel (const int32_t* __restrict__ probs, const int nt, const int n,
                                    const int need_conserve, const int na, const int sb,
@@ -2322,6 +2335,28 @@ void caas_reduce_accum_lds_kernel (const int32_t* __restrict__ probs, const int 
     const int64_t beg = (static_cast<int64_t>(blockIdx.x)*kAccumNsb + b)*sb;
     if (beg >= n) break;
     const int cnt = static_cast<int>(min(static_cast<int64_t>(sb), n - beg));  // whole groups
+    if (VEC == 2) {
+      typedef double __attribute__((ext_vector_type(2))) d2;
+      const d2* __restrict__ vin = reinterpret_cast<const d2*>(qin + beg);
+      const d2* __restrict__ vlo = reinterpret_cast<const d2*>(qlo + beg);
+      const d2* __restrict__ vhi = reinterpret_cast<const d2*>(qhi + beg);
+      const d2* __restrict__ vpv = reinterpret_cast<const d2*>(qpv ? qpv + beg : nullptr);
+      d2* __restrict__ vout = reinterpret_cast<d2*>(qm + beg);
+      for (int i2 = threadIdx.x; i2 < cnt/2; i2 += kBlock) {
+        const d2 q = __builtin_nontemporal_load(vin + i2), lo = __builtin_nontemporal_load(vlo + i2),
+          hi = __builtin_nontemporal_load(vhi + i2);
+        d2 cl;
+        cl.x = rmin(hi.x, rmax(lo.x, q.x));
+        cl.y = rmin(hi.y, rmax(lo.y, q.y));
+        vout[i2] = cl;
+        const d2 term = qpv ? __builtin_nontemporal_load(vpv + i2) : q;
+        const int i = 2*i2, j0 = i + i/na, j1 = (i + 1) + (i + 1)/na;
+        sm[j0] = cl.x; sm[j1] = cl.y;
+        sm[rowlen + j0] = term.x; sm[rowlen + j1] = term.y;
+        sm[2*rowlen + j0] = lo.x; sm[2*rowlen + j1] = lo.y;
+        sm[3*rowlen + j0] = hi.x; sm[3*rowlen + j1] = hi.y;
+      }
+    } else
     for (int i = threadIdx.x; i < cnt; i += kBlock) {
       // streamed once: non-temporal, as in caas_reduce_kernel
       const double q = __builtin_nontemporal_load(qin + beg + i), lo = __builtin_nontemporal_load(qlo + beg + i),
@@ -2613,8 +2648,11 @@ int cedr_hip_tree_up_rows_sums (const cedr_hip_stage* st, int32_t nfields, const
       return 0;
     };
     const bool sums = all_sums && ! zero_init;
+    const bool sums_zi = all_sums && zero_init;  // (the BFB reducer: every node is 0 + kid0 + kid1)
     int e;
-    if (ft32) e = sums ? go(tree_up_micro_kernel<32, false, true>) : go(tree_up_micro_kernel<32, false, false>);
+    if (sums_zi && ! ft32)
+      e = in_rows ? go(tree_up_micro_kernel<kUpFT, true, true, true>) : go(tree_up_micro_kernel<kUpFT, false, true, true>);
+    else if (ft32) e = sums ? go(tree_up_micro_kernel<32, false, true>) : go(tree_up_micro_kernel<32, false, false>);
     else if (in_rows) e = sums ? go(tree_up_micro_kernel<kUpFT, true, true>) : go(tree_up_micro_kernel<kUpFT, true, false>);
     else e = sums ? go(tree_up_micro_kernel<kUpFT, false, true>) : go(tree_up_micro_kernel<kUpFT, false, false>);
     if (e) return e;
@@ -2943,8 +2981,15 @@ int cedr_hip_caas_reduce_local_accum (const int32_t* probs, int32_t nt, int32_t 
     const int sb = kAccumSub/na*na;
     const size_t lds = sizeof(double)*4*static_cast<size_t>(sb + sb/na);
     const int64_t per = static_cast<int64_t>(sb)*kAccumNsb;
-    hipLaunchKernelGGL(caas_reduce_accum_lds_kernel, dim3(static_cast<unsigned>((n + per - 1)/per), nt),
-                       dim3(kBlock), lds, stream, probs, nt, n, need_conserve, na, sb, d, qm_src, send);
+    // 16-byte accesses when every row and every sub-block starts on a 16-byte boundary
+    const bool vec = n % 2 == 0 && sb % 2 == 0 && reinterpret_cast<uintptr_t>(d) % 16 == 0 &&
+      ( ! qm_src || reinterpret_cast<uintptr_t>(qm_src) % 16 == 0);
+    if (vec)
+      hipLaunchKernelGGL(caas_reduce_accum_lds_kernel<2>, dim3(static_cast<unsigned>((n + per - 1)/per), nt),
+                         dim3(kBlock), lds, stream, probs, nt, n, need_conserve, na, sb, d, qm_src, send);
+    else
+      hipLaunchKernelGGL(caas_reduce_accum_lds_kernel<1>, dim3(static_cast<unsigned>((n + per - 1)/per), nt),
+                         dim3(kBlock), lds, stream, probs, nt, n, need_conserve, na, sb, d, qm_src, send);
     return launch_status();
   }
   const int total = 2*nt*(n/na);
