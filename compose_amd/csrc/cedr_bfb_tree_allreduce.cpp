@@ -120,6 +120,10 @@ void BfbTreeAllReducerHip::allreduce (const Real* send, Real* recv, const bool t
     cedr_k_check(cedr_hip_tree_apex_sum(eng_->apex_stage(), gathered, eng_->apex_src(), nfield_, 1, recv, s));
     return;
   }
+  if (eng_->takes_root_out()) {  // one rank: the top tile's launch writes the root's record to recv itself
+    eng_->up(nfield_, m_->op.data(), bd, true, s, in_rows, false, recv);
+    return;
+  }
   eng_->up(nfield_, m_->op.data(), bd, true, s, in_rows);
   eng_->bcast_root(nfield_, bd, s);  // level mode only: cedr_bfb_tree_allreduce.cpp:68-76, the way back down
   // The root's record is the result on every rank (:68-76 read it back from

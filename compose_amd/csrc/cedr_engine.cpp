@@ -148,6 +148,7 @@ void TreeEngine::upload () {
     apex_src_.upload(src);
     apex_my_in_.upload(mine);
   }
+  if (takes_root_out()) root_slot_dev_.upload(std::vector<int32_t>(1, plan_.root_slot));
   uploaded_ = true;
 }
 
@@ -164,15 +165,20 @@ bool TreeEngine::first_stage_takes_rows () const {
 // The local stages, leaves->root. pack_roots: the fused top tile's launch also packs this rank's
 // boundary roots' records into sendbuf_ (the gather launch fused in).
 void TreeEngine::up_local (int32_t nfields, const uint8_t* op_dev, double* data, bool zero_init,
-                           hipStream_t stream, const double* const* in_rows, bool skip_top, bool pack_roots) {
+                           hipStream_t stream, const double* const* in_rows, bool skip_top, bool pack_roots,
+                           double* root_out) {
   cedr_throw_if( ! uploaded_, "TreeEngine::upload was not called");
   for (size_t i = 0; i < local_.size(); ++i) {
     if (plan_.local[i].top) {
       if (skip_top) continue;
-      cedr_k_check(cedr_hip_tree_top_up(&local_[i]->h, &local_[i]->tile0, nfields, op_dev, stride_, data, zero_init,
-                                        pack_roots ? static_cast<int32_t>(plan_.my_root_slots.size()) : 0,
-                                        pack_roots ? my_root_slots_.data() : nullptr,
-                                        pack_roots ? sendbuf_.data() : nullptr, stream));
+      if (root_out)  // single rank: the root's record straight to the caller's buffer
+        cedr_k_check(cedr_hip_tree_top_up(&local_[i]->h, &local_[i]->tile0, nfields, op_dev, stride_, data, zero_init,
+                                          1, root_slot_dev_.data(), root_out, stream));
+      else
+        cedr_k_check(cedr_hip_tree_top_up(&local_[i]->h, &local_[i]->tile0, nfields, op_dev, stride_, data, zero_init,
+                                          pack_roots ? static_cast<int32_t>(plan_.my_root_slots.size()) : 0,
+                                          pack_roots ? my_root_slots_.data() : nullptr,
+                                          pack_roots ? sendbuf_.data() : nullptr, stream));
     } else {
       cedr_k_check(cedr_hip_tree_up_rows_sums(&local_[i]->h, nfields, op_dev, stride_, data,
                                               i == 0 ? in_rows : nullptr, plan_.nlcl, zero_init, all_sums_, stream));
@@ -181,10 +187,11 @@ void TreeEngine::up_local (int32_t nfields, const uint8_t* op_dev, double* data,
 }
 
 void TreeEngine::up (int32_t nfields, const uint8_t* op_dev, double* data, bool zero_init,
-                     hipStream_t stream, const double* const* in_rows, bool skip_top) {
+                     hipStream_t stream, const double* const* in_rows, bool skip_top, double* root_out) {
   const bool xch = ! plan_.level_mode && ! top_.empty();
   if (xch) size_exchange_buffers(nfields);
-  up_local(nfields, op_dev, data, zero_init, stream, in_rows, skip_top, xch && has_top());
+  cedr_throw_if(root_out && ! takes_root_out(), "root_out needs a single-rank plan with a fused top tile");
+  up_local(nfields, op_dev, data, zero_init, stream, in_rows, skip_top, xch && has_top(), root_out);
   if (plan_.level_mode) { up_levels(nfields, op_dev, data, zero_init, stream); return; }
   if (top_.empty()) return;
   exchange(nfields, data, stream, has_top());

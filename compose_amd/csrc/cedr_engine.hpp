@@ -49,8 +49,12 @@ public:
   // its inputs from in_rows[f][slot] instead of data (zero-copy mode).
   // skip_top: leave out the fused top tile (has_top()); the caller sweeps it itself (QLT on one
   // rank: cedr_hip_qlt_top mode 1 re-forms the tile's sums and computes the root in its one launch).
+  // root_out (device, nfields doubles; single rank with a fused top tile only -- see takes_root_out()): the
+  // top tile's launch also writes the root's record there, which saves the caller a gather launch.
   void up(int32_t nfields, const uint8_t* op_dev, double* data, bool zero_init,
-          hipStream_t stream, const double* const* in_rows = nullptr, bool skip_top = false);
+          hipStream_t stream, const double* const* in_rows = nullptr, bool skip_top = false,
+          double* root_out = nullptr);
+  bool takes_root_out () const { return has_top() && plan_.nranks == 1 && ! plan_.level_mode; }
   // The fused top tile (plan::Stage::top): the last local stage, swept by the tracer-parallel top
   // kernels in one launch per direction.
   bool has_top () const { return ! plan_.local.empty() && plan_.local.back().top; }
@@ -103,7 +107,7 @@ private:
   void exchange(int32_t nfields, double* data, hipStream_t stream, bool gathered = false);
   void size_exchange_buffers(int32_t nfields);
   void up_local(int32_t nfields, const uint8_t* op_dev, double* data, bool zero_init, hipStream_t stream,
-                const double* const* in_rows, bool skip_top, bool pack_roots);
+                const double* const* in_rows, bool skip_top, bool pack_roots, double* root_out = nullptr);
   struct StepOff { size_t nodes, outs, ins; };
   std::vector<StepOff> lvl_off_;
   dev::Buffer<int32_t> lvl_nodes_, lvl_outs_, lvl_ins_;
