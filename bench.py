@@ -440,12 +440,13 @@ def main():
                         launch="first stage: %d workgroups (tiles)" % dom["launch"],
                         rocprof="every stage runs the same sweep kernels (qlt_down_sp_kernel / tree_up_micro_kernel),"
                                 " so rocprofv3 --stats averages all stages under one name; "
-                                "profiles/r02_kernel_stats_by_grid.csv splits the same trace by launch grid "
-                                "(tools/kernel_stats_by_grid.py)")
+                                "profiles/r03_kernel_stats_by_grid.csv splits the same trace by kernel instantiation "
+                                "and launch grid (tools/kernel_stats_by_grid.py)")
         if dom["kernel"] == "qlt_down_kernel":
-            roofline["bound_note"] = ("reported against the HBM roofline, the metric's roofline; the measured limiter of "
-                                      "this kernel is fp64 instruction issue: with cache-resident inputs it is as "
-                                      "slow (profiles/r02_down_experiments.md)")
+            roofline["bound_note"] = ("reported against the HBM roofline, the metric's roofline; with cache-resident "
+                                      "inputs this kernel is as slow (profiles/r02_down_experiments.md 1): its limiter "
+                                      "is the dependent chain of node problems per chunk at the occupancy 96 VGPRs allow "
+                                      "(profiles/r03_experiments.md 2-3)")
 
     # Pack / unpack either side of run() (reported apart from `value`).
     def timed_sync(fn, reps=5):

@@ -1078,6 +1078,19 @@ void qlt_down_micro_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st
 # define CEDR_DOWN_SP_WAVES1 5  // ... and the 1-tracer-per-wave build
 #endif
 
+// The node problem of the shape-preserving root->leaves kernel: the straight-line form, except in the zero-copy
+// (ROWS) build, which has no register to spare for it (8 spilled VGPRs in its loop with it, none without:
+// QLT::run on bound arrays 1.15 against 1.02 ms).
+template <bool WAVE>
+__device__ __forceinline__
+void node_problem_sel (const double p_lo, const double p_orig, const double p_hi, const double Qm,
+                       const KidRho r0, const double lo0, const double or0, const double hi0,
+                       const KidRho r1, const double lo1, const double or1, const double hi1,
+                       double& x0, double& x1, const bool prefer) {
+  if (WAVE) node_problem_mass_wave(p_lo, p_orig, p_hi, Qm, r0, lo0, or0, hi0, r1, lo1, or1, hi1, x0, x1, prefer);
+  else node_problem_mass(p_lo, p_orig, p_hi, Qm, r0, lo0, or0, hi0, r1, lo1, or1, hi1, x0, x1, prefer);
+}
+
 template <int TW, bool ROWS>
 __global__ __launch_bounds__(kBlock, TW == 1 ? CEDR_DOWN_SP_WAVES1 : CEDR_DOWN_SP_WAVES2)
 void qlt_down_sp_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st,
@@ -1249,7 +1262,7 @@ void qlt_down_sp_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st,
         double* K0 = R + 4*c0;
         double* K1 = R + 4*c1;
         double x0, x1;
-        node_problem_mass_wave(P[0], P[1], P[2], P[3], r0, K0[0], K0[1], K0[2], r1, K1[0], K1[1], K1[2],
+        node_problem_sel< ! ROWS>(P[0], P[1], P[2], P[3], r0, K0[0], K0[1], K0[2], r1, K1[0], K1[1], K1[2],
                           x0, x1, prefer);
         K0[3] = x0;
         K1[3] = x1;
@@ -1275,16 +1288,16 @@ void qlt_down_sp_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st,
       if ((any2 && m.shape == 2) || (any3 && m.shape == 3)) {
         const KidRho kp{cellrho[6*kWave + lane], cellrho[7*kWave + lane], cellrho[8*kWave + lane]};
         if (any2 && m.shape == 2)
-          node_problem_mass_wave(RR[0], RR[1], RR[2], Xr, kt, T[0], T[1], T[2],
+          node_problem_sel< ! ROWS>(RR[0], RR[1], RR[2], Xr, kt, T[0], T[1], T[2],
                             kp, cur[s][2][0], cur[s][2][1], cur[s][2][2], Xt, Xp, prefer);
         if (any3 && m.shape == 3)
-          node_problem_mass_wave(RR[0], RR[1], RR[2], Xr, kp, cur[s][2][0], cur[s][2][1], cur[s][2][2],
+          node_problem_sel< ! ROWS>(RR[0], RR[1], RR[2], Xr, kp, cur[s][2][0], cur[s][2][1], cur[s][2][2],
                             kt, T[0], T[1], T[2], Xp, Xt, prefer);
       }
       if (m.shape >= 1) {
         const KidRho ku{cellrho[0*kWave + lane], cellrho[1*kWave + lane], cellrho[2*kWave + lane]};
         const KidRho kv{cellrho[3*kWave + lane], cellrho[4*kWave + lane], cellrho[5*kWave + lane]};
-        node_problem_mass_wave(T[0], T[1], T[2], Xt, ku, cur[s][0][0], cur[s][0][1], cur[s][0][2],
+        node_problem_sel< ! ROWS>(T[0], T[1], T[2], Xt, ku, cur[s][0][0], cur[s][0][1], cur[s][0][2],
                           kv, cur[s][1][0], cur[s][1][1], cur[s][1][2], Xu, Xv, prefer);
       }
       double* __restrict__ const orow = (ROWS ? outL[biw] : r2l + static_cast<size_t>(r2lL[biw])*S) + tile.in0;

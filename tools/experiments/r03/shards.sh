@@ -12,4 +12,4 @@ done
 for ov in start down; do
   timeout -k 10 200 python3 bench.py --steps 100 --warmup 5 --no-cpu-baseline --check --ncells 187500 --overlap $ov > $O/s_187500_$ov.json 2> $O/b.err && { echo -n "187500 cells, two streams ($ov): "; python3 tests/showbench.py $O/s_187500_$ov.json | grep "value"; }
 done
-timeout -k 10 200 python3 tools/chain_rank0_of_8.py 2>&1 | grep -v amdgpu.ids | tail -24
+timeout -k 10 200 python3 tools/chain_rank0_of_8.py 2>&1 | grep -v amdgpu.ids | tail -44

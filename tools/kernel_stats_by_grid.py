@@ -14,13 +14,15 @@ import sys
 src, dst = sys.argv[1], sys.argv[2]
 agg = collections.defaultdict(list)
 for r in csv.DictReader(open(src)):
-    m = re.search(r"(\w+_kernel)", r["Kernel_Name"])
+    m = re.search(r"(\w+_kernel)(<[^>(]*>)?", r["Kernel_Name"])
     if not m or not m.group(1).startswith(("qlt_", "tree_", "caas_", "gather_slots", "scatter_slots",
                                             "copy_slots")):
         continue
     grid = "%sx%sx%s" % (r["Grid_Size_X"], r["Grid_Size_Y"], r["Grid_Size_Z"])
     wg = int(r["Workgroup_Size_X"])
-    agg[(m.group(1), grid, wg, r["VGPR_Count"], r["LDS_Block_Size"])].append(
+    # template arguments kept: the zero-copy (ROWS = true) builds of the sweeps run with the same grid as the packed
+    # ones in bench.py's pack/unpack leg and must not be averaged into the rows the roofline is about
+    agg[(m.group(1) + (m.group(2) or ""), grid, wg, r["VGPR_Count"], r["LDS_Block_Size"])].append(
         int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 rows = sorted(agg.items(), key=lambda kv: -sum(kv[1]))
 with open(dst, "w", newline="") as f:
