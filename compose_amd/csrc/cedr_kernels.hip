@@ -1540,7 +1540,9 @@ constexpr int kTopBlock = 1024;
 // Diagnostic build only: wall-clock stamps (10 ns units) of workgroup 0's thread 0 at the phase
 // boundaries of qlt_top_kernel (slots 0..31) and tree_top_up_kernel (32..63).
 __device__ unsigned long long g_top_stamps[64];
-# define TSTAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_top_stamps[i] = wall_clock64(); } while (0)
+// (slots 60 / 61: the shader clock at stamps 0 / 30 of qlt_top_kernel: clock rate = cycles / wall time)
+# define TSTAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) { g_top_stamps[i] = wall_clock64(); \
+    if ((i) == 0) g_top_stamps[60] = clock64(); if ((i) == 30) g_top_stamps[61] = clock64(); } } while (0)
 #else
 # define TSTAMP(i)
 #endif
@@ -1854,27 +1856,40 @@ void qlt_top_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st, const
     const bool awant = k == 4 || fk >= 0;  // the apex sums include Qm_prev: its root is computed here
     const double* __restrict__ const frow = l2r + static_cast<size_t>(fk < 0 ? 0 : fk)*S + in0;
     const int ok = k < 4 ? rule_of(k) : 0;
+    // (a level's offsets and kid indices do not depend on the sums: they are read one level ahead, so that
+    // only the kids' values and the write are on the chain from level to level)
+    int a = 0, n = 0;
+    uint32_t kk = 0;
+    if (narrow < tile.nlvl) {
+      a = M.lvlL[narrow]; n = M.lvlL[narrow+1] - a;
+      kk = lane < n ? M.kidsL[a + lane] : 0;
+    }
     for (int lv = narrow; lv < tile.nlvl; ++lv) {
-      const int a = M.lvlL[lv], n = M.lvlL[lv+1] - a;
+      int a2 = 0, n2 = 0;
+      uint32_t kk2 = 0;
+      if (lv + 1 < tile.nlvl) {
+        a2 = M.lvlL[lv+1]; n2 = M.lvlL[lv+2] - a2;
+        kk2 = lane < n2 ? M.kidsL[a2 + lane] : 0;
+      }
       if (lane < n) {
         const int j = a + lane;
         double r = 0.0;
         if (want) {
-          const uint32_t kk = M.kidsL[j];
           const int c0 = kk & 0xffff, c1 = kk >> 16;
           if (k < 4) r = combine(ok, 0, c0 < nleaf ? frow[c0] : recs[4*(c0 - nleaf) + k],
                                  c1 < nleaf ? frow[c1] : recs[4*(c1 - nleaf) + k]);
           else r = (c0 < nleaf ? rrow[c0] : rho[c0 - nleaf]) + (c1 < nleaf ? rrow[c1] : rho[c1 - nleaf]);
         }
         if (k < 4) recs[4*j + k] = r;
-        else { rho[j] = r; const double w = 1.0/r; rw[j] = w; rq[j] = 1.0/w; }
+        else rho[j] = r;
       }
       wave_lds_order();
+      a = a2; n = n2; kk = kk2;
     }
     if (mode == 2) {
       if (lane < an) {
         if (k < 4) arec[4*lane + k] = av;
-        else { arho[lane] = av; const double w = 1.0/av; arw[lane] = w; arq[lane] = 1.0/w; }
+        else arho[lane] = av;
       }
       wave_lds_order();
       for (int lv = 0; lv < A.tile.nlvl; ++lv) {
@@ -1883,18 +1898,25 @@ void qlt_top_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st, const
           const uint32_t kk = akids[a + lane];
           const int c0 = kk & 0xffff, c1 = kk >> 16, me = an + a + lane;
           if (k < 4) arec[4*me + k] = awant ? combine(ok, 0, arec[4*c0 + k], arec[4*c1 + k]) : 0.0;
-          else { const double r = arho[c0] + arho[c1]; arho[me] = r; const double w = 1.0/r; arw[me] = w; arq[me] = 1.0/w; }
+          else arho[me] = arho[c0] + arho[c1];
         }
         wave_lds_order();
       }
     }
   }
-  // reciprocals of the wide levels' densities (the narrow ones have theirs)
-  for (int j = tid; j < M.lvlL[narrow]; j += kTopBlock) {
+  // reciprocals of the densities (kept off the narrow levels' chain: two dependent divisions per level)
+  __syncthreads();
+  for (int j = tid; j < nint; j += kTopBlock) {
     const double w = 1.0/rho[j];
     rw[j] = w;
     rq[j] = 1.0/w;
   }
+  if (mode == 2)
+    for (int i = tid; i < an + A.tile.nint; i += kTopBlock) {
+      const double w = 1.0/arho[i];
+      arw[i] = w;
+      arq[i] = 1.0/w;
+    }
   __syncthreads();
   TSTAMP(2);
 
@@ -1950,15 +1972,26 @@ void qlt_top_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st, const
   const int nsteps = asteps + tile.nlvl;
   const int nnarrow = asteps + (tile.nlvl - narrow);  // the first steps: narrow
   TSTAMP(3);
+  // a step's offsets and this thread's kid indices do not depend on the step before: read one step ahead
+  auto describe = [&] (const int s, int& a, int& n, uint32_t& kk) {
+    const bool ap = s < asteps;
+    const int lv = ap ? asteps - 1 - s : tile.nlvl - 1 - (s - asteps);
+    const int32_t* const LV = ap ? alvl : M.lvlL;
+    a = LV[lv]; n = LV[lv+1] - a;
+    kk = (tid < n && (ap || lv > 0)) ? (ap ? akids : M.kidsL)[a + tid] : 0;
+  };
+  int a_nx = 0, n_nx = 0;
+  uint32_t kk_nx = 0;
+  if (nsteps > 0) describe(0, a_nx, n_nx, kk_nx);
   for (int s = 0; s < nsteps; ++s) {
     if (s < 24) TSTAMP(4 + s);
     const bool narrow_step = s < nnarrow;
+    const int a = a_nx, n = n_nx;
+    const uint32_t kk_c = kk_nx;
+    if (s + 1 < nsteps && (wave == 0 || s + 1 >= nnarrow)) describe(s + 1, a_nx, n_nx, kk_nx);
     if (narrow_step && wave != 0) continue;
     const bool ap = s < asteps;
     const int lv = ap ? asteps - 1 - s : tile.nlvl - 1 - (s - asteps);
-    const uint32_t* const KD = ap ? akids : M.kidsL;
-    const int32_t* const LV = ap ? alvl : M.lvlL;
-    const int a = LV[lv], n = LV[lv+1] - a;
     const int thr = ap ? 0 : nleaf;      // kid ids below thr are inputs in global memory
     const int off = ap ? 0 : nleaf;      // LDS index of kid c: c - off
     const int pb = ap ? an : 0;          // LDS index of this level's node j: pb + j
@@ -1988,8 +2021,7 @@ void qlt_top_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st, const
         cc[e] = c0r[e]; krh[e] = r0[e]; klo[e] = f0[e][0]; kor[e] = f0[e][1]; khi[e] = f0[e][2];
       }
     } else if (act) {
-      const uint32_t kk = KD[a + tid];
-      cc[0] = kk & 0xffff; cc[1] = kk >> 16;
+      cc[0] = kk_c & 0xffff; cc[1] = kk_c >> 16;
 #pragma unroll
       for (int e = 0; e < 2; ++e)
         if (cc[e] < thr) {
@@ -2321,9 +2353,12 @@ __global__ void caas_reduce_accum_kernel (const int32_t* __restrict__ probs, con
 // reference's order, 0 + c0 + c1 + ..., so the partial sums a UserAllReducer sees
 // are bit-identical. LDS rows are padded by one double per group, which keeps the
 // group-strided reads of the second phase off a single bank.
-constexpr int kAccumSub = 1024;  // cells per sub-block (upper bound; a multiple of n_accum is used)
+#ifndef CEDR_CAAS_ACCUM_SUB
+# define CEDR_CAAS_ACCUM_SUB 1024
+#endif
+constexpr int kAccumSub = CEDR_CAAS_ACCUM_SUB;  // cells per sub-block (upper bound; a multiple of n_accum is used)
 #ifndef CEDR_CAAS_ACCUM_NSB
-# define CEDR_CAAS_ACCUM_NSB 4
+# define CEDR_CAAS_ACCUM_NSB 1
 #endif
 constexpr int kAccumNsb = CEDR_CAAS_ACCUM_NSB;     // sub-blocks per workgroup
 template <int VEC>  // 2: 16-byte accesses, two cells per thread and pass (needs n and sb even, 16-byte aligned rows)
@@ -2716,7 +2751,8 @@ int cedr_hip_qlt_down_rows (const cedr_hip_qlt_layout* lay, const cedr_hip_stage
                                         static_cast<size_t>(TTm)*pitch) +
       (in_rows ? sizeof(double*)*static_cast<size_t>(lay->l2rndps + lay->nt) : 0);
     if (ldsm > 160*1024) return static_cast<int>(hipErrorInvalidValue);
-    const dim3 gridm(xcd_grid(st->ntiles), chunk_split(st->ntiles, (nt + TTm - 1)/TTm, kSplitDown));
+    static const int split_down = [] { const char* v = std::getenv("CEDR_HIP_SPLIT_DOWN"); return v ? std::atoi(v) : kSplitDown; }();
+    const dim3 gridm(xcd_grid(st->ntiles), chunk_split(st->ntiles, (nt + TTm - 1)/TTm, split_down));
     auto go = [&] (auto kernel) -> int {
       int e = set_lds_limit(kernel, ldsm);
       if (e) return e;

@@ -39,5 +39,7 @@ for label, q in (("single rank 187.5k (mode 1)", mk(ca.Parallel.self_(), n//P, 1
         print("  %-28s +%.2f us" % (names.get(i, "down step %d done" % (i - 4) if i > 4 else "down starts") if i != 30 else "end", (t[i] - prev_t)*0.01))
         prev_t = t[i]
     print("  total %.2f us" % ((t[30] - t[0])*0.01))
+    if t[61] > t[60]:
+        print("  shader clock over the launch: %.0f MHz" % ((t[61] - t[60])/((t[30] - t[0])*0.01)))
     if t[32]:
         print("  tree_top_up: loads %.2f us, level 0 %.2f us, other levels %.2f us" % (0, (t[33]-t[32])*0.01, (t[34]-t[33])*0.01))
