@@ -219,8 +219,13 @@ def main():
     if a.same_gpu:
         local_rank = 0
     if local_rank >= torch.cuda.device_count():
-        raise SystemExit("rank %d: no GPU %d on this node (%d visible); --gpus must not exceed the GPU count"
-                         % (rank, local_rank, torch.cuda.device_count()))
+        if torch.cuda.device_count() == 1 and world > 1:
+            # a launcher that hands every rank its own GPU through the visibility mask (ROCR / HIP_VISIBLE_DEVICES):
+            # the one device this process sees is this rank's
+            local_rank = 0
+        else:
+            raise SystemExit("rank %d: no GPU %d on this node (%d visible); --gpus must not exceed the GPU count"
+                             % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     torch.zeros(1, device=device)  # initialise the HIP context before the library is used
