@@ -9,7 +9,7 @@ import json, sys, shutil, os
 H = sys.argv[1].strip(); O = "gpurun_out/r03final"; P = "profiles"
 def jcopy(src, dst):
     d = json.load(open(os.path.join(O, src)))
-    if isinstance(d, dict): d = dict(head=H, **d)
+    if isinstance(d, dict): d = dict(d, head=H)
     json.dump(d, open(os.path.join(P, dst), "w"), indent=1)
 def tcopy(src, dst, comment="# "):
     if not os.path.exists(os.path.join(O, src)): return

@@ -12,7 +12,7 @@ rm -rf $O; mkdir -p $O
 HEAD=$(cat .head_sha 2>/dev/null | tr '\n' ' ')
 echo "HEAD $HEAD" | tee $O/HEAD.txt
 timeout -k 10 400 python3 bench.py --check > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"; python3 tests/showbench.py $O/bench.json
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$O/kt" -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline > $O/bench_kt.json 2> $O/bench_kt.err; echo "kernel trace rc=$?"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$O/kt" -- python3 bench.py --steps 40 --warmup 5 --no-cpu-baseline > $O/bench_kt.json 2> $O/bench_kt.err; echo "kernel trace rc=$?"
 python3 tools/kernel_stats_by_grid.py $O/kt/*/*kernel_trace.csv $O/kernel_stats_by_grid.csv | head -16
 cp $O/kt/*/*kernel_stats.csv $O/kernel_stats.csv 2>/dev/null
 for c in FETCH_SIZE WRITE_SIZE; do
