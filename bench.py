@@ -11,7 +11,7 @@ spawned before anything touches a GPU; rank 0's JSON line is relayed), and
 `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` works too.
 The global problem is sharded contiguously over ranks (strong scaling). The data
 path uses the library's own RCCL communicator (one all-gather per QLT run, one
-all-reduce per CAAS run; at N > 1 the two CDRs run on two streams by default and the
+all-reduce per CAAS run; the two CDRs run on two streams by default, at every N, and the
 library orders the communicator's collectives across them with events, --serial = one stream);
 torch.distributed (gloo) is only the control plane (unique-id broadcast, barriers,
 max over ranks). A transport that fails ends the run with a non-zero exit code.
@@ -45,16 +45,19 @@ def parse():
     ap.add_argument("--cpu-cells", type=int, default=0,
                     help="cells of the CPU-baseline run (same tracer count); 0 = the configuration itself")
     ap.add_argument("--check", action="store_true", help="verify properties of the results")
-    ap.add_argument("--overlap", nargs="?", const="start", default=None, choices=["start", "down"],
+    ap.add_argument("--overlap", nargs="?", const="start", default=None, choices=["start", "down", "mid"],
                     help="QLT and CAAS on two concurrent streams instead of back to back on one: 'start' = both "
                          "begin together (measured on one GPU: 2-3 %% at 1.5M cells, 10 %% at the 187.5k-cell "
                          "shard of an 8-GPU run); 'down' = CAAS::run begins when QLT::run reaches its first-stage "
                          "root->leaves sweep (fp64-issue bound, so the memory-bound CAAS kernels fit beside it). With N > 1 "
                          "the two CDRs still share ONE communicator, whose collectives the library orders "
-                         "with events across streams. Default: one stream at N = 1, 'start' at N > 1 (the "
-                         "latency of each CDR's one small collective then hides behind the other CDR's kernels).")
+                         "with events across streams; 'mid' = CAAS::run begins when QLT::run has finished its "
+                         "first-stage leaves->root sweep. Default: 'start' at every N (round 3, with CAAS's small "
+                         "workgroups: 1.61 -> 1.56 ms per step at 1.5M cells on one GPU, 0.239 -> 0.221 ms at the 187.5k-cell "
+                         "shard; at N > 1 the latency of each CDR's one small collective also hides behind the other "
+                         "CDR's kernels). The roofline leg always runs on one stream.")
     ap.add_argument("--serial", action="store_true",
-                    help="QLT::run then CAAS::run back to back on one stream, also at N > 1")
+                    help="QLT::run then CAAS::run back to back on one stream")
     ap.add_argument("--comm", choices=["rccl", "gloo"], default="rccl",
                     help="data-path transport for N > 1: the library's RCCL communicator (default) or, "
                          "for rehearsals on one GPU, host-staged torch.distributed/gloo callbacks")
@@ -201,8 +204,8 @@ def spawn_ranks(a):
 
 def main():
     a = parse()
-    if a.gpus > 1 and a.overlap is None and not a.serial:
-        a.overlap = "start"
+    if a.overlap is None and not a.serial:
+        a.overlap = "start"  # at every N, so that the N = 1 and N > 1 numbers are the same program
     if a.gpus > 1 and "RANK" not in os.environ:
         spawn_ranks(a)  # does not return
     import torch
@@ -319,7 +322,7 @@ def main():
     caas.set_Qm(Qm, Qm_min, Qm_max, Qm_prev)
     caas.set_Qm_source(Qm)  # every run() reads the pristine Qm: identical work each step
     torch.cuda.synchronize()
-    # Default: QLT::run then CAAS::run on one stream. --overlap (N = 1): each CDR on its own stream.
+    # Default: each CDR on its own stream, both starting together; --serial: QLT::run then CAAS::run on one stream.
     streams = None
     if a.overlap:
         # (experiment knob: CEDR_BENCH_PRIO="q,c" = HIP stream priorities of the QLT and the CAAS stream,
@@ -336,6 +339,8 @@ def main():
             dist.barrier()
 
     down_ev = qlt.sweep_down_event() if (streams and a.overlap == "down") else None
+    if streams and a.overlap == "mid":  # CAAS::run starts when QLT::run has finished its first-stage leaves->root sweep
+        down_ev = qlt.sweep_mid_event()
 
     def step():
         qlt.run()

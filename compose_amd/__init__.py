@@ -109,6 +109,7 @@ _SIGS = {
     "cedr_qlt_run": (C.c_int, [_vp]),
     "cedr_qlt_set_stream": (C.c_int, [_vp, _vp]),
     "cedr_qlt_sweep_down_event": (_vp, [_vp]),
+    "cedr_qlt_sweep_mid_event": (_vp, [_vp]),
     "cedr_stream_wait_event": (C.c_int, [_vp, _vp]),
     "cedr_qlt_get_device_op": (C.c_int, [_vp, C.POINTER(_QltDeviceOp)]),
     "cedr_qlt_set_rhom_bulk": (C.c_int, [_vp, _vp]),
@@ -653,6 +654,11 @@ class QLT(_CDR):
         """hipEvent_t run() records just before its first-stage root->leaves sweep (fp64-issue bound): another
         stream that waits for it runs memory-bound work side by side with that sweep."""
         return _handle(lib().cedr_qlt_sweep_down_event(self.h), "sweep_down_event")
+
+    def sweep_mid_event(self):
+        """hipEvent_t run() records after its first-stage leaves->root sweep: what follows until the first-stage
+        root->leaves sweep are small, latency-bound launches that leave most of the GPU idle."""
+        return _handle(lib().cedr_qlt_sweep_mid_event(self.h), "sweep_mid_event")
 
     def __init__(self, parallel, ncells, tree, prefer_mass_con_to_bounds=False):
         self.p, self.tree = parallel, tree

@@ -225,6 +225,7 @@ int cedr_qlt_gci2lci (void* h, int gci) { CEDR_TRY return Q(h).gci2lci(gci); CED
 int cedr_qlt_run (void* h) { CEDR_TRY Q(h).run(); return 0; CEDR_CATCH(-1) }
 int cedr_qlt_set_stream (void* h, cedr_stream_t s) { Q(h).set_stream(s); return 0; }
 void* cedr_qlt_sweep_down_event (void* h) { CEDR_TRY return Q(h).sweep_down_event(); CEDR_CATCH(nullptr) }
+void* cedr_qlt_sweep_mid_event (void* h) { CEDR_TRY return Q(h).sweep_mid_event(); CEDR_CATCH(nullptr) }
 int cedr_stream_wait_event (cedr_stream_t s, void* ev) {
   return static_cast<int>(hipStreamWaitEvent(static_cast<hipStream_t>(s), static_cast<hipEvent_t>(ev), 0));
 }

@@ -183,7 +183,9 @@ void TreeEngine::up_local (int32_t nfields, const uint8_t* op_dev, double* data,
       cedr_k_check(cedr_hip_tree_up_rows_sums(&local_[i]->h, nfields, op_dev, stride_, data,
                                               i == 0 ? in_rows : nullptr, plan_.nlcl, zero_init, all_sums_, stream));
     }
+    if (i == 0 && first_ev_) cedr_throw_if(hipEventRecord(first_ev_, stream) != hipSuccess, "hipEventRecord failed");
   }
+  if (local_.empty() && first_ev_) cedr_throw_if(hipEventRecord(first_ev_, stream) != hipSuccess, "hipEventRecord failed");
 }
 
 void TreeEngine::up (int32_t nfields, const uint8_t* op_dev, double* data, bool zero_init,

@@ -57,6 +57,8 @@ public:
   bool takes_root_out () const { return has_top() && plan_.nranks == 1 && ! plan_.level_mode; }
   // The fused top tile (plan::Stage::top): the last local stage, swept by the tracer-parallel top
   // kernels in one launch per direction.
+  // Recorded (if set) on the sweep's stream right after the first local leaves->root stage of every up().
+  void set_after_first_stage_event (hipEvent_t e) { first_ev_ = e; }
   bool has_top () const { return ! plan_.local.empty() && plan_.local.back().top; }
   const cedr_hip_stage* top_stage () const { return &local_.back()->h; }
   const cedr_hip_tile* top_tile () const { return &local_.back()->tile0; }  // host copy of its descriptor
@@ -115,6 +117,7 @@ private:
   void up_levels(int32_t nfields, const uint8_t* op_dev, double* data, bool zero_init, hipStream_t stream);
   dev::Buffer<double> sendbuf_, recvbuf_, bcast_, bcast_send_;
   dev::Buffer<int32_t> root_slot_dev_;
+  hipEvent_t first_ev_ = nullptr;
   int32_t xfields_ = 0;
   std::vector<mpi::Comm::P2P> ops_;  // scratch of level_exchange (reused: no allocation per round)
   bool uploaded_ = false;

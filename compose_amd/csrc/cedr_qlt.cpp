@@ -44,7 +44,8 @@ struct QLTHip::Impl {
   bool bound_rows = false;  // the kernels read / write the caller's rows directly
   std::vector<Int> packed_tracers;  // caller indices of the t-only tracers
   hipEvent_t down_ev = nullptr;     // see QLTHip::sweep_down_event
-  ~Impl () { if (down_ev) (void) hipEventDestroy(down_ev); }
+  hipEvent_t mid_ev = nullptr;      // see QLTHip::sweep_mid_event
+  ~Impl () { if (down_ev) (void) hipEventDestroy(down_ev); if (mid_ev) (void) hipEventDestroy(mid_ev); }
 };
 
 // ---- MetaData: reference cedr_qlt.cpp:85-157, cedr_qlt_inl.hpp:101-117 ----
@@ -293,6 +294,12 @@ void QLTHip::set_stream (hipStream_t stream) { d_->stream = stream; }
 hipEvent_t QLTHip::sweep_down_event () {
   if ( ! d_->down_ev) cedr_hip_check(hipEventCreateWithFlags(&d_->down_ev, hipEventDisableTiming));
   return d_->down_ev;
+}
+
+hipEvent_t QLTHip::sweep_mid_event () {
+  if ( ! d_->mid_ev) cedr_hip_check(hipEventCreateWithFlags(&d_->mid_ev, hipEventDisableTiming));
+  eng_->set_after_first_stage_event(d_->mid_ev);
+  return d_->mid_ev;
 }
 
 void QLTHip::set_rhom_bulk (const Real* rhom) {

@@ -103,6 +103,9 @@ public:
   // with independent memory-bound work (CAAS on other tracers, a halo copy) lets another stream
   // wait for it (hipStreamWaitEvent) so that the two run side by side. Created on first call.
   hipEvent_t sweep_down_event();
+  // The same for the point where run() has finished its first-stage leaves->root sweep, i.e. the start of its
+  // short middle part of small, latency-bound launches (stages 2.., top), during which most of the GPU is idle.
+  hipEvent_t sweep_mid_event();
   // Bulk forms of the DeviceOp calls over all local cells; device arrays laid
   // out [tracer][cell] in caller tracer order (rhom: [cell]).
   void set_rhom_bulk(const Real* rhom);

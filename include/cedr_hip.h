@@ -328,6 +328,9 @@ int cedr_qlt_set_stream(void* qlt, cedr_stream_t stream);
  * (cedr_stream_wait_event = hipStreamWaitEvent) to run independent memory-bound work, e.g. CAAS,
  * side by side with that sweep. Owned by the QLT. */
 void* cedr_qlt_sweep_down_event(void* qlt);
+/* the same for the end of run()'s first-stage leaves->root sweep: what follows until the first-stage root->leaves
+ * sweep is a short series of small, latency-bound launches that leave most of the GPU idle */
+void* cedr_qlt_sweep_mid_event(void* qlt);
 int cedr_stream_wait_event(cedr_stream_t stream, void* event);
 /* DeviceOp for C callers: the values a device kernel needs to do set/get itself. */
 typedef struct {

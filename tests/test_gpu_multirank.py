@@ -77,6 +77,18 @@ def test_bench_self_spawned_ranks_same_gpu(gpu, nranks, extra):
     assert d["config"]["rccl_nranks"] == 0 and d["config"]["transport"].startswith("gloo-host-staged")
 
 
+@pytest.mark.parametrize("extra,streams", [([], 2), (["--serial"], 1), (["--overlap", "down"], 2),
+                                           (["--overlap", "mid"], 2)])
+def test_bench_one_gpu_stream_modes(gpu, extra, streams):
+    """One GPU: QLT::run and CAAS::run on two streams by default (both start together; or CAAS waits for the event
+    QLT::run records before its first-stage root->leaves sweep / after its first-stage leaves->root sweep), or back
+    to back on one stream. Every mode passes the result checks."""
+    res, d = _bench(["--steps", "3", "--warmup", "1", "--ncells", "40000", "--ntracers", "6", "--check",
+                     "--no-cpu-baseline"] + extra)
+    assert res.returncode == 0, res.stdout[-1500:] + res.stderr[-1500:]
+    assert d["n_gpus"] == 1 and d["check_ok"] is True and d["config"]["streams"] == streams
+
+
 def test_bench_under_torch_distributed_run(gpu):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", "29502", os.path.join(ROOT, "bench.py"),

@@ -6,7 +6,7 @@ cd "$R"
 mkdir -p gpurun_out/r03env
 n=$1
 for rep in 1 2; do
-for cfg in "serial" "start 0,0" "down 0,0" "start 0,-1" "down 0,-1" "start -1,0" "down -1,0"; do
+for cfg in ${CFGS:-"serial" "start 0,0" "down 0,0" "mid 0,0" "mid 0,-1" "mid -1,0"}; do
   set -- $cfg
   if [ "$1" = serial ]; then args="--serial"; pr="0,0"; else args="--overlap $1"; pr=$2; fi
   CEDR_BENCH_PRIO=$pr timeout -k 10 200 python3 bench.py --steps 100 --warmup 5 --no-cpu-baseline --check --ncells $n $args > gpurun_out/r03env/ov.json 2> gpurun_out/r03env/ov.err || { tail -3 gpurun_out/r03env/ov.err; continue; }

@@ -31,10 +31,14 @@ for key, name in (("DOWNT", "qlt_down_kernel"), ("UPT", "tree_up_kernel"), ("RED
     v[key] = "%.2f" % (t[name]["hbm_bytes"]/1e9)
 sh = open(os.path.join(O, "shards_and_chain.txt")).read()
 def step(pat): return float(re.search(pat + r".*?ms/step ([0-9.]+)", sh).group(1))
-s15, s75, s37, s18 = step("1500000 cells:"), step("750000 cells:"), step("375000 cells:"), step("187500 cells:")
-s18o = step(r"two streams \(start\):")
-v.update(S1500="%.3f" % s15, S750="%.3f" % s75, S375="%.3f" % s37, S187="%.3f" % s18, S187O="%.3f" % s18o,
-         R750="%.2f" % (s15/s75), R375="%.2f" % (s15/s37), R187="%.2f" % (s15/s18), R187O="%.2f" % (s15/s18o))
+s15, s75, s37, s18 = [step("%d cells, one stream:" % n) for n in (1500000, 750000, 375000, 187500)]
+t15, t75, t37, t18 = [step(r"%d cells, two streams \(default\):" % n) for n in (1500000, 750000, 375000, 187500)]
+v.update(S1500="%.3f" % s15, S750="%.3f" % s75, S375="%.3f" % s37, S187="%.3f" % s18,
+         R750="%.2f" % (s15/s75), R375="%.2f" % (s15/s37), R187="%.2f" % (s15/s18),
+         T1500="%.3f" % t15, T750="%.3f" % t75, T375="%.3f" % t37, T187="%.3f" % t18,
+         Q750="%.2f" % (t15/t75), Q375="%.2f" % (t15/t37), Q187="%.2f" % (t15/t18))
+bs = json.load(open(os.path.join(O, "bench_serial.json")))
+v["STEPSER"] = "%.3f" % bs["ms_per_step"]; v["VALUESER"] = "%.2fe10" % (bs["value"]/1e10)
 def opt(pat):
     m = re.search(pat, sh)
     return m.group(1) if m else "n/a"
