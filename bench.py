@@ -348,8 +348,26 @@ def main():
             ca.stream_wait_event(streams[1].cuda_stream, down_ev)
         caas.run()
 
-    for _ in range(a.warmup):
+    for _ in range(max(a.warmup, 1) if world > 1 else a.warmup):
         step()
+    if world > 1:
+        # Fail fast instead of hanging: the first steps over the real transport must complete. (A communicator
+        # whose collectives stall -- a rank that died, an ordering problem across the two streams -- would
+        # otherwise sit in synchronize() until the caller's timeout.)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(device))
+        evs = [ev]
+        for st in (streams or ()):
+            e2 = torch.cuda.Event()
+            e2.record(st)
+            evs.append(e2)
+        deadline = time.monotonic() + 120.0
+        while not all(e.query() for e in evs):
+            if time.monotonic() > deadline:
+                print("bench.py: rank %d: the warm-up steps did not complete within 120 s over '%s'%s" %
+                      (rank, transport, "; try --serial (one stream)" if streams else ""), file=sys.stderr, flush=True)
+                os._exit(6)
+            time.sleep(0.002)
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
