@@ -40,7 +40,8 @@ typedef struct {
   int32_t in0, nleaf, out, nint, kids_off, lvl_off, nlvl, micro_off, nout, outs_off;
 } cedr_hip_tile;
 
-/* One stage: tiles that are swept by one kernel launch (max_nleaf <= 256).
+/* One stage: tiles that are swept by one kernel launch (max_nleaf <= 256; the fused top tile, a stage of one plain
+ * tile for cedr_hip_tree_top_up / cedr_hip_qlt_top: <= 2048).
  * Arrays are device memory. kids: 2 local node ids per internal node; lvlptr: per tile nlvl+1
  * offsets. micro != NULL marks a MICRO stage: the nleaf (<= 64) inputs of a
  * tile's LDS tree are subtrees of <= 3 consecutive cells, one per lane, handled
