@@ -1081,6 +1081,14 @@ void qlt_down_micro_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st
 // The node problem of the shape-preserving root->leaves kernel: the straight-line form, except in the zero-copy
 // (ROWS) build, which has no register to spare for it (8 spilled VGPRs in its loop with it, none without:
 // QLT::run on bound arrays 1.15 against 1.02 ms).
+#ifndef CEDR_REC_STRIDE
+# define CEDR_REC_STRIDE 5
+#endif
+// Doubles per LDS record {lo, orig, hi, X} of the shape-preserving kernel. 5 = one double of padding: with 4 the lanes
+// of a wave on consecutive nodes are 32 bytes apart and every fourth collides on an LDS bank (bank conflicts in 45 % of
+// the LDS-active cycles, round 2's counters); 40 bytes apart they do not: first-stage sweep 0.457 -> 0.445 ms. (Round 2
+// tried four separate arrays instead: slower, it doubles the LDS instructions.)
+constexpr int kRS = CEDR_REC_STRIDE;
 template <bool WAVE>
 __device__ __forceinline__
 void node_problem_sel (const double p_lo, const double p_orig, const double p_hi, const double Qm,
@@ -1219,7 +1227,7 @@ void qlt_down_sp_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st,
       for (int f = 0; f < 3; ++f) {
         const double t = cur[s][0][f] + cur[s][1][f];
         const double r = m.shape <= 0 ? cur[s][0][f] : (m.shape == 1 ? t : t + cur[s][2][f]);
-        if (lane < nleaf) Rw[4*lane + f] = r;
+        if (lane < nleaf) Rw[kRS*lane + f] = r;
       }
     }
     for (int lv = 0; lv < tile.nlvl; ++lv) {
@@ -1230,9 +1238,9 @@ void qlt_down_sp_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st,
         double* const Rw = recs + (wave + kNW*s)*pitch;
         for (int j = a + lane; j < b; j += kWave) {
           const uint32_t kk = kidsL[j];
-          const double* K0 = Rw + 4*(kk & 0xffff);
-          const double* K1 = Rw + 4*(kk >> 16);
-          double* me = Rw + 4*(nleaf + j);
+          const double* K0 = Rw + kRS*(kk & 0xffff);
+          const double* K1 = Rw + kRS*(kk >> 16);
+          double* me = Rw + kRS*(nleaf + j);
           // (all six reads before the first write: the compiler must assume me aliases K0 / K1 and would
           // otherwise wait for LDS three times)
           const double a0 = K0[0], a1 = K0[1], a2 = K0[2], b0 = K1[0], b1 = K1[1], b2 = K1[2];
@@ -1244,7 +1252,7 @@ void qlt_down_sp_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st,
 #pragma unroll
     for (int s = 0; s < TW; ++s) {
       const int biw = c*TT + wave + kNW*s;
-      if (biw < nt && lane < tile.nout) recs[(wave + kNW*s)*pitch + 4*onodeL[lane] + 3] = Xout[s];
+      if (biw < nt && lane < tile.nout) recs[(wave + kNW*s)*pitch + kRS*onodeL[lane] + 3] = Xout[s];
     }
     __syncthreads();
     // ---- node problems of the LDS levels, from the tile's outputs down, (node, tracer) items
@@ -1258,9 +1266,9 @@ void qlt_down_sp_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st,
         const uint32_t kk = kidsL[j];
         const int c0 = kk & 0xffff, c1 = kk >> 16, me = nleaf + j;
         const KidRho r0{rho[c0], rw[c0], rq[c0]}, r1{rho[c1], rw[c1], rq[c1]};
-        const double* P = R + 4*me;
-        double* K0 = R + 4*c0;
-        double* K1 = R + 4*c1;
+        const double* P = R + kRS*me;
+        double* K0 = R + kRS*c0;
+        double* K1 = R + kRS*c1;
         double x0, x1;
         node_problem_sel< ! ROWS>(P[0], P[1], P[2], P[3], r0, K0[0], K0[1], K0[2], r1, K1[0], K1[1], K1[2],
                           x0, x1, prefer);
@@ -1282,7 +1290,7 @@ void qlt_down_sp_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st,
         T[f] = cur[s][0][f] + cur[s][1][f];
         RR[f] = m.shape <= 0 ? cur[s][0][f] : (m.shape == 1 ? T[f] : T[f] + cur[s][2][f]);
       }
-      const double Xr = recs[(wave + kNW*s)*pitch + 4*lane + 3];
+      const double Xr = recs[(wave + kNW*s)*pitch + kRS*lane + 3];
       double Xt = Xr, Xu = Xr, Xv = 0, Xp = 0;
       const KidRho kt{cellrho[9*kWave + lane], cellrho[10*kWave + lane], cellrho[11*kWave + lane]};
       if ((any2 && m.shape == 2) || (any3 && m.shape == 3)) {
@@ -1706,6 +1714,10 @@ void tree_top_up_kernel (const cedr_hip_stage st, const cedr_hip_tile tile, cons
 // the end of the dependent chain of levels waits for memory. The root->leaves part is ONE loop over the
 // apex tile's levels (mode 2) and then the top tile's, with a single inlined copy of the node problem:
 // the kernel runs once per step on a cold instruction cache, so its code size is launch latency.
+#ifndef CEDR_TOP_REC_STRIDE
+# define CEDR_TOP_REC_STRIDE 5
+#endif
+constexpr int kTRS = CEDR_TOP_REC_STRIDE;  // doubles per LDS record of qlt_top_kernel (4 + padding, as kRS)
 struct TopApex {
   cedr_hip_stage st;
   cedr_hip_tile tile;
@@ -1793,7 +1805,7 @@ void qlt_top_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st, const
   double* const rw = rho + MI;
   double* const rq = rw + MI;
   double* const recs = rq + MI;          // [nint][4]
-  double* const apx = recs + 4*static_cast<size_t>(MI);
+  double* const apx = recs + kTRS*static_cast<size_t>(MI);
   // apex part of the LDS (mode 2): every node of the apex tile, inputs first
   const int AM = A.st.max_nodes;
   uint32_t* const akids = reinterpret_cast<uint32_t*>(apx);
@@ -1812,7 +1824,7 @@ void qlt_top_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st, const
   }
   if (tid < n0) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) recs[4*tid + k] = combine(rule_of(k), 0, f0[0][k], f0[1][k]);
+    for (int k = 0; k < 4; ++k) recs[kTRS*tid + k] = combine(rule_of(k), 0, f0[0][k], f0[1][k]);
     rho[tid] = r0[0] + r0[1];
   }
   __syncthreads();
@@ -1834,10 +1846,10 @@ void qlt_top_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st, const
         if (want) {
           const uint32_t kk = M.kidsL[a + (q >> 2)];
           const int c0 = kk & 0xffff, c1 = kk >> 16;
-          r = combine(ok, 0, c0 < nleaf ? frow[c0] : recs[4*(c0 - nleaf) + k],
-                      c1 < nleaf ? frow[c1] : recs[4*(c1 - nleaf) + k]);
+          r = combine(ok, 0, c0 < nleaf ? frow[c0] : recs[kTRS*(c0 - nleaf) + k],
+                      c1 < nleaf ? frow[c1] : recs[kTRS*(c1 - nleaf) + k]);
         }
-        recs[4*(a + (q >> 2)) + k] = r;
+        recs[kTRS*(a + (q >> 2)) + k] = r;
       }
       if (tid < n) {
         const uint32_t kk = M.kidsL[a + tid];
@@ -1876,11 +1888,11 @@ void qlt_top_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st, const
         double r = 0.0;
         if (want) {
           const int c0 = kk & 0xffff, c1 = kk >> 16;
-          if (k < 4) r = combine(ok, 0, c0 < nleaf ? frow[c0] : recs[4*(c0 - nleaf) + k],
-                                 c1 < nleaf ? frow[c1] : recs[4*(c1 - nleaf) + k]);
+          if (k < 4) r = combine(ok, 0, c0 < nleaf ? frow[c0] : recs[kTRS*(c0 - nleaf) + k],
+                                 c1 < nleaf ? frow[c1] : recs[kTRS*(c1 - nleaf) + k]);
           else r = (c0 < nleaf ? rrow[c0] : rho[c0 - nleaf]) + (c1 < nleaf ? rrow[c1] : rho[c1 - nleaf]);
         }
-        if (k < 4) recs[4*j + k] = r;
+        if (k < 4) recs[kTRS*j + k] = r;
         else rho[j] = r;
       }
       wave_lds_order();
@@ -1888,7 +1900,7 @@ void qlt_top_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st, const
     }
     if (mode == 2) {
       if (lane < an) {
-        if (k < 4) arec[4*lane + k] = av;
+        if (k < 4) arec[kTRS*lane + k] = av;
         else arho[lane] = av;
       }
       wave_lds_order();
@@ -1897,7 +1909,7 @@ void qlt_top_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st, const
         if (lane < n) {
           const uint32_t kk = akids[a + lane];
           const int c0 = kk & 0xffff, c1 = kk >> 16, me = an + a + lane;
-          if (k < 4) arec[4*me + k] = awant ? combine(ok, 0, arec[4*c0 + k], arec[4*c1 + k]) : 0.0;
+          if (k < 4) arec[kTRS*me + k] = awant ? combine(ok, 0, arec[kTRS*c0 + k], arec[kTRS*c1 + k]) : 0.0;
           else arho[me] = arho[c0] + arho[c1];
         }
         wave_lds_order();
@@ -1935,7 +1947,7 @@ void qlt_top_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st, const
     for (int k = tid; k < tile.nout; k += kTopBlock) {
       const int node = st.outs[tile.outs_off + k];
       const double x = r2l[rb*S + tile.out + k];
-      if (node >= nleaf) recs[4*(node - nleaf) + 3] = x;
+      if (node >= nleaf) recs[kTRS*(node - nleaf) + 3] = x;
       else put_input(node, x, qlo, qhi);
     }
   } else if (mode == 1) {
@@ -1943,17 +1955,17 @@ void qlt_top_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st, const
     // record's entry 3 already holds the former
     const int node = root_node;
     if (node >= nleaf) {
-      const double* const R = recs + 4*(node - nleaf);
+      const double* const R = recs + kTRS*(node - nleaf);
       if (t_only) { qlo = R[0]; qhi = R[2]; }
-      if (tid == 0 && ! cons) recs[4*(node - nleaf) + 3] = R[1];
+      if (tid == 0 && ! cons) recs[kTRS*(node - nleaf) + 3] = R[1];
     } else {  // a one-cell tree: the root is the input itself
       const int fo = field_of(cons ? 3 : 1);
       if (t_only) { qlo = l2r[lb*S + in0 + node]; qhi = l2r[(lb + 2)*S + in0 + node]; }
       if (tid == 0) put_input(node, l2r[fo*S + in0 + node], qlo, qhi);
     }
   } else {
-    if (t_only) { qlo = arec[4*aroot]; qhi = arec[4*aroot + 2]; }
-    if (tid == 0 && ! cons) arec[4*aroot + 3] = arec[4*aroot + 1];
+    if (t_only) { qlo = arec[kTRS*aroot]; qhi = arec[kTRS*aroot + 2]; }
+    if (tid == 0 && ! cons) arec[kTRS*aroot + 3] = arec[kTRS*aroot + 1];
   }
   __syncthreads();
 
@@ -2005,10 +2017,10 @@ void qlt_top_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st, const
       // there by that stage) and, for this tile's outputs, into the tile. (<= 64 of them: wave 0's lanes.)
       if (narrow_step) wave_lds_order(); else __syncthreads();
       if (tid < A.nmine) {
-        const double x = arec[4*my_in_r + 3];
+        const double x = arec[kTRS*my_in_r + 3];
         r2l[rb*S + my_slot_r] = x;
         if (t_only) { r2l[(rb + 1)*S + my_slot_r] = qlo; r2l[(rb + 2)*S + my_slot_r] = qhi; }
-        if (my_node_r >= nleaf) recs[4*(my_node_r - nleaf) + 3] = x;
+        if (my_node_r >= nleaf) recs[kTRS*(my_node_r - nleaf) + 3] = x;
         else if (my_node_r >= 0) put_input(my_node_r, x, qlo, qhi);
       }
     }
@@ -2039,11 +2051,11 @@ void qlt_top_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st, const
       } else if (act) {
         const int ci = cc[e] - off;
         kr[e] = KidRho{RH[ci], RW[ci], RQ[ci]};
-        klo[e] = RC[4*ci]; kor[e] = RC[4*ci + 1]; khi[e] = RC[4*ci + 2];
+        klo[e] = RC[kTRS*ci]; kor[e] = RC[kTRS*ci + 1]; khi[e] = RC[kTRS*ci + 2];
       }
     }
     const int me = pb + a + (act ? tid : 0);
-    const double* const P = RC + 4*me;
+    const double* const P = RC + kTRS*me;
     const double plo = P[0], por = P[1], phi = P[2], prh = RH[me];
     // the results of the level above: wave 0's own (narrow steps), or everybody's
     if (narrow_step) wave_lds_order(); else __syncthreads();
@@ -2055,14 +2067,14 @@ void qlt_top_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st, const
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
       if (regs || cc[e] < thr) put_input(cc[e], xs[e], qlo, qhi);
-      else RC[4*(cc[e] - off) + 3] = xs[e];
+      else RC[kTRS*(cc[e] - off) + 3] = xs[e];
     }
   }
   TSTAMP(30);
   if (mode == 2 && tile.nlvl == 0) {  // (a top tile of copies only: the hand-over still has to happen)
     __syncthreads();
     if (tid < A.nmine) {
-      const double x = arec[4*my_in_r + 3];
+      const double x = arec[kTRS*my_in_r + 3];
       r2l[rb*S + my_slot_r] = x;
       if (t_only) { r2l[(rb + 1)*S + my_slot_r] = qlo; r2l[(rb + 2)*S + my_slot_r] = qhi; }
       if (my_node_r >= 0) put_input(my_node_r, x, qlo, qhi);
@@ -2762,13 +2774,15 @@ int cedr_hip_qlt_down_rows (const cedr_hip_qlt_layout* lay, const cedr_hip_stage
     };
     int e;
     if (sp) {
-      const size_t ldss = ldsm + sizeof(int32_t)*(2*static_cast<size_t>(nt) + kWave);
+      const int pitchs = pitch_for(kRS*st->max_nodes);
+      const size_t ldss = ldsm + sizeof(double)*static_cast<size_t>(TTm)*(pitchs - pitch) +
+        sizeof(int32_t)*(2*static_cast<size_t>(nt) + kWave);
       if (ldss > 160*1024) return static_cast<int>(hipErrorInvalidValue);
       auto gosp = [&] (auto kernel) -> int {
         int e2 = set_lds_limit(kernel, ldss);
         if (e2) return e2;
         hipLaunchKernelGGL(kernel, gridm, dim3(kBlock), ldss, stream,
-                           *lay, *st, l2r, r2l, in_rows, out_rows, nrow, pitch);
+                           *lay, *st, l2r, r2l, in_rows, out_rows, nrow, pitchs);
         return 0;
       };
       if (tw == 1) e = in_rows ? gosp(qlt_down_sp_kernel<1, true>) : gosp(qlt_down_sp_kernel<1, false>);
@@ -2850,7 +2864,7 @@ int cedr_hip_qlt_top (const cedr_hip_qlt_layout* lay, const cedr_hip_stage* st, 
   if (lay->nt == 0) return 0;
   if ( ! top_stage_ok(st, tile) || mode < 0 || mode > 2 || (mode == 1 && tile->nout != 1))
     return static_cast<int>(hipErrorInvalidValue);
-  size_t lds = sizeof(double)*(8*static_cast<size_t>(st->max_nint) + 1);
+  size_t lds = sizeof(double)*((4 + kTRS)*static_cast<size_t>(st->max_nint) + 1);
   TopApex A;
   A.st = *st; A.tile = *tile; A.recv = nullptr; A.src = nullptr; A.nmine = 0; A.my_in = nullptr; A.my_slot = nullptr;
   if (mode == 2) {
@@ -2859,7 +2873,7 @@ int cedr_hip_qlt_top (const cedr_hip_qlt_layout* lay, const cedr_hip_stage* st, 
         (nmine > 0 && ( ! my_in || ! my_slot)))
       return static_cast<int>(hipErrorInvalidValue);
     A.st = *apex; A.tile = *apex_tile; A.recv = recv; A.src = src; A.nmine = nmine; A.my_in = my_in; A.my_slot = my_slot;
-    lds += sizeof(double)*(static_cast<size_t>(apex->max_nint) + 1 + 7*static_cast<size_t>(apex->max_nodes));
+    lds += sizeof(double)*(static_cast<size_t>(apex->max_nint) + 1 + (3 + kTRS)*static_cast<size_t>(apex->max_nodes));
   }
   if (lds > 160*1024) return static_cast<int>(hipErrorInvalidValue);
   int e = set_lds_limit(qlt_top_kernel, lds);
