@@ -25,6 +25,15 @@ constexpr int kBlock = 256;          // 4 wavefronts
 constexpr int kWave = 64;
 using namespace cedr_dev;
 
+#ifndef CEDR_REC_STRIDE
+# define CEDR_REC_STRIDE 5
+#endif
+// Doubles per LDS record {lo, orig, hi, X} of the shape-preserving kernel. 5 = one double of padding: with 4 the lanes
+// of a wave on consecutive nodes are 32 bytes apart and every fourth collides on an LDS bank (bank conflicts in 45 % of
+// the LDS-active cycles, round 2's counters); 40 bytes apart they do not: first-stage sweep 0.457 -> 0.445 ms. (Round 2
+// tried four separate arrays instead: slower, it doubles the LDS instructions.)
+constexpr int kRS = CEDR_REC_STRIDE;
+
 // ------------------------------------------------------------- tile sweeps
 // One workgroup sweeps one tile. It keeps a CHUNK of FT fields (leaves->root)
 // or TT tracers (root->leaves) of that tile in LDS and spreads the (node, field)
@@ -922,7 +931,7 @@ void qlt_down_micro_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st
       for (int f = 0; f < 3; ++f) {
         const double t = cur[s][0][f] + cur[s][1][f];
         const double r = m.shape <= 0 ? cur[s][0][f] : (m.shape == 1 ? t : t + cur[s][2][f]);
-        if (lane < nleaf) Rw[4*lane + f] = r;
+        if (lane < nleaf) Rw[kRS*lane + f] = r;
       }
     }
     STAMP(1);  // loads arrived + micro sums
@@ -959,9 +968,9 @@ void qlt_down_micro_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st
       for (int q = threadIdx.x; q < nitems; q += kBlock) {
         const int j = a + (q >> Log2<TT>::value);
         const uint32_t kk = kidsL[j];
-        const double* K0 = R + 4*(kk & 0xffff);
-        const double* K1 = R + 4*(kk >> 16);
-        double* me = R + 4*(nleaf + j);
+        const double* K0 = R + kRS*(kk & 0xffff);
+        const double* K1 = R + kRS*(kk >> 16);
+        double* me = R + kRS*(nleaf + j);
         if (sp) { me[0] = K0[0] + K1[0]; me[2] = K0[2] + K1[2]; }
         me[1] = K0[1] + K1[1];
       }
@@ -970,7 +979,7 @@ void qlt_down_micro_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st
 #pragma unroll
     for (int i = 0; i < NO; ++i) {
       const int k = kout + i*(kBlock/TT);
-      if (live && k < tile.nout) R[4*st.outs[tile.outs_off + k] + 3] = Xout[i];
+      if (live && k < tile.nout) R[kRS*st.outs[tile.outs_off + k] + 3] = Xout[i];
     }
     __syncthreads();
     STAMP(3);  // phase A + outputs' masses
@@ -983,9 +992,9 @@ void qlt_down_micro_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st
         const uint32_t kk = kidsL[j];
         const int c0 = kk & 0xffff, c1 = kk >> 16, me = nleaf + j;
         const KidRho r0{rho[c0], rw[c0], rq[c0]}, r1{rho[c1], rw[c1], rq[c1]};
-        const double* P = R + 4*me;
-        double* K0 = R + 4*c0;
-        double* K1 = R + 4*c1;
+        const double* P = R + kRS*me;
+        double* K0 = R + kRS*c0;
+        double* K1 = R + kRS*c1;
         double x0, x1;
         if (t_only)
           solve_node(pt, rho[me], qlo, P[1], qhi, P[3], r0, qlo, K0[1], qhi,
@@ -1026,7 +1035,7 @@ void qlt_down_micro_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st
         T[f] = cur[s][0][f] + cur[s][1][f];
         RR[f] = m.shape <= 0 ? cur[s][0][f] : (m.shape == 1 ? T[f] : T[f] + cur[s][2][f]);
       }
-      const double Xr = recs[(wave + kNW*s)*pitch + 4*lane + 3];
+      const double Xr = recs[(wave + kNW*s)*pitch + kRS*lane + 3];
       double Xu = Xr, Xv = 0, Xp = 0;
       if (t_onlyw)
         micro_solves<true>(m.shape, any2, any3, ptw, rr, ku, kv, kp, kt, cur[s], T, RR, Xr, qlw, qhw, prefer,
@@ -1081,14 +1090,7 @@ void qlt_down_micro_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st
 // The node problem of the shape-preserving root->leaves kernel: the straight-line form, except in the zero-copy
 // (ROWS) build, which has no register to spare for it (8 spilled VGPRs in its loop with it, none without:
 // QLT::run on bound arrays 1.15 against 1.02 ms).
-#ifndef CEDR_REC_STRIDE
-# define CEDR_REC_STRIDE 5
-#endif
-// Doubles per LDS record {lo, orig, hi, X} of the shape-preserving kernel. 5 = one double of padding: with 4 the lanes
-// of a wave on consecutive nodes are 32 bytes apart and every fourth collides on an LDS bank (bank conflicts in 45 % of
-// the LDS-active cycles, round 2's counters); 40 bytes apart they do not: first-stage sweep 0.457 -> 0.445 ms. (Round 2
-// tried four separate arrays instead: slower, it doubles the LDS instructions.)
-constexpr int kRS = CEDR_REC_STRIDE;
+
 template <bool WAVE>
 __device__ __forceinline__
 void node_problem_sel (const double p_lo, const double p_orig, const double p_hi, const double Qm,
@@ -2744,7 +2746,7 @@ int cedr_hip_qlt_down_rows (const cedr_hip_qlt_layout* lay, const cedr_hip_stage
   if (( ! in_rows) != ( ! out_rows) || (in_rows && ( ! st->micro || nrow < 3)))
     return static_cast<int>(hipErrorInvalidValue);
   const size_t mn = st->max_nodes;
-  const int pitch = pitch_for(4*st->max_nodes);
+  const int pitch = pitch_for(kRS*st->max_nodes);
   if (st->micro) {
     if (st->max_nleaf > kWave) return static_cast<int>(hipErrorInvalidValue);
     // Two builds: 2 tracers per wave (8 per chunk) or 1 (4 per chunk). A chunk costs the
@@ -2774,9 +2776,8 @@ int cedr_hip_qlt_down_rows (const cedr_hip_qlt_layout* lay, const cedr_hip_stage
     };
     int e;
     if (sp) {
-      const int pitchs = pitch_for(kRS*st->max_nodes);
-      const size_t ldss = ldsm + sizeof(double)*static_cast<size_t>(TTm)*(pitchs - pitch) +
-        sizeof(int32_t)*(2*static_cast<size_t>(nt) + kWave);
+      const int pitchs = pitch;
+      const size_t ldss = ldsm + sizeof(int32_t)*(2*static_cast<size_t>(nt) + kWave);
       if (ldss > 160*1024) return static_cast<int>(hipErrorInvalidValue);
       auto gosp = [&] (auto kernel) -> int {
         int e2 = set_lds_limit(kernel, ldss);
@@ -2795,19 +2796,21 @@ int cedr_hip_qlt_down_rows (const cedr_hip_qlt_layout* lay, const cedr_hip_stage
     if (e) return e;
     return launch_status();
   }
-  const size_t lds = sizeof(double)*(meta_doubles(st) + 3*mn + static_cast<size_t>(kDownTT)*pitch);
+  // (plain tiles hold up to 511 nodes: their records stay four doubles, padded ones would not fit the LDS)
+  const int pitchp = pitch_for(4*st->max_nodes);
+  const size_t lds = sizeof(double)*(meta_doubles(st) + 3*mn + static_cast<size_t>(kDownTT)*pitchp);
   if (lds > 160*1024) return static_cast<int>(hipErrorInvalidValue);
   const dim3 grid(st->ntiles, chunk_split(st->ntiles, (lay->nt + kDownTT - 1)/kDownTT, kSplitUp));
   if (st->max_nleaf <= 128) {
     int e = set_lds_limit(qlt_down_kernel<kDownTT, 2>, lds);
     if (e) return e;
     hipLaunchKernelGGL((qlt_down_kernel<kDownTT, 2>), grid, dim3(kBlock), lds, stream,
-                       *lay, *st, l2r, r2l, pitch);
+                       *lay, *st, l2r, r2l, pitchp);
   } else {
     int e = set_lds_limit(qlt_down_kernel<kDownTT, 4>, lds);
     if (e) return e;
     hipLaunchKernelGGL((qlt_down_kernel<kDownTT, 4>), grid, dim3(kBlock), lds, stream,
-                       *lay, *st, l2r, r2l, pitch);
+                       *lay, *st, l2r, r2l, pitchp);
   }
   return launch_status();
 }
