@@ -4,6 +4,7 @@
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -54,7 +55,10 @@ const RcclApi& rccl () {
   static std::once_flag once;
   std::call_once(once, [] () {
     api.ok = api.p2p = false;
-    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
+    // CEDR_HIP_RCCL_LIB: the library to bind instead (a site's own librccl build; the tests' double).
+    const char* const given = std::getenv("CEDR_HIP_RCCL_LIB");
+    void* h = (given && *given) ? dlopen(given, RTLD_NOW | RTLD_LOCAL) : dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
+    if (given && *given && ! h) return;  // named but not loadable: an error, not a silent fallback
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     // RTLD_LOCAL: a process that later loads ANOTHER librccl (PyTorch bundles its own) must not
     // have that copy's symbols resolved against this one (seen as a double free at exit).

@@ -61,9 +61,22 @@ class ThreadComm:
                                            lambda sends, recvs: self.exchange(rank, sends, recvs))
 
 
-def run_ranks(nranks, body, timeout=600):
+class RcclThreads(ThreadComm):
+    """The same ranks-as-threads harness over the product's OWN RCCL communicator class: every thread
+    makes ca.Parallel.rccl(id, rank, P). Only meaningful when the process binds the tests' double of RCCL
+    (CEDR_HIP_RCCL_LIB = tests/cpp/libfake_rccl.so): the real one refuses two ranks on one device."""
+
+    def __init__(self, ca, nranks, timeout=600):
+        ThreadComm.__init__(self, nranks, timeout)
+        self.uid = ca.Parallel.rccl_unique_id()
+
+    def parallel(self, ca, rank):
+        return ca.Parallel.rccl(self.uid, rank, self.P)
+
+
+def run_ranks(nranks, body, timeout=600, comm=None):
     """body(rank, comm) on nranks threads; re-raises the first failure."""
-    comm = ThreadComm(nranks, timeout)
+    comm = comm or ThreadComm(nranks, timeout)
     errs = [None] * nranks
     res = [None] * nranks
 
@@ -89,7 +102,7 @@ def run_ranks(nranks, body, timeout=600):
 
 
 def run_qlt(ca, nranks, ncells, types, v, prefer=False, pseudorandom=False, imbalanced=False, nrepeat=1,
-            partial=False, want_level_mode=None):
+            partial=False, want_level_mode=None, comm=None):
     """Global arrays in, global result out; every rank owns what Tree.make_1d gives it.
     partial: every rank passes only its part of the tree (tree::Node::level)."""
     out = np.zeros_like(v.Qm)
@@ -117,12 +130,12 @@ def run_qlt(ca, nranks, ncells, types, v, prefer=False, pseudorandom=False, imba
         ca.synchronize()
         out[:, g] = od.numpy((len(types), len(g)))
         return len(g)
-    counts = run_ranks(nranks, body)
+    counts = run_ranks(nranks, body, comm=comm)
     assert sum(counts) == ncells
     return out
 
 
-def run_caas(ca, nranks, ncells, types, v):
+def run_caas(ca, nranks, ncells, types, v, comm=None):
     """Contiguous split of the global arrays; returns the global result."""
     out = np.zeros_like(v.Qm)
     bounds = [ncells * r // nranks for r in range(nranks + 1)]
@@ -144,5 +157,5 @@ def run_caas(ca, nranks, ncells, types, v):
         c.get_Qm(od)
         ca.synchronize()
         out[:, sl] = od.numpy((len(types), n))
-    run_ranks(nranks, body)
+    run_ranks(nranks, body, comm=comm)
     return out, [bounds[r + 1] - bounds[r] for r in range(nranks)]
