@@ -58,6 +58,9 @@ def parse():
                          "CDR's kernels). The roofline leg always runs on one stream.")
     ap.add_argument("--serial", action="store_true",
                     help="QLT::run then CAAS::run back to back on one stream")
+    ap.add_argument("--cu-split", type=int, default=int(os.environ.get("CEDR_BENCH_CU_SPLIT", "0")), choices=[0, 1, 2, 3],
+                    help="two-stream modes: CAAS::run on this many of every four groups of eight compute units, "
+                         "QLT::run on the others (CU-masked streams); 0 = both on all of them")
     ap.add_argument("--comm", choices=["rccl", "gloo"], default="rccl",
                     help="data-path transport for N > 1: the library's RCCL communicator (default) or, "
                          "for rehearsals on one GPU, host-staged torch.distributed/gloo callbacks")
@@ -235,6 +238,7 @@ def main():
 
     ncells, nt = a.ncells, a.ntracers
     keep = []  # objects the callbacks refer to
+    keep_streams = []
 
     def make_cdrs(par, par2):
         tree = ca.Tree.make_1d(ncells, world, False, False)  # contiguous ownership, balanced
@@ -329,6 +333,16 @@ def main():
         # lower number = higher priority, torch's range is -1..0)
         pq, pc = [int(x) for x in os.environ.get("CEDR_BENCH_PRIO", "0,0").split(",")]
         streams = (torch.cuda.Stream(device=device, priority=pq), torch.cuda.Stream(device=device, priority=pc))
+        if a.cu_split:
+            # Each CDR on its own share of the compute units: of every four groups of eight CUs CAAS::run gets
+            # cu_split, QLT::run the rest (uniform over the XCDs whichever way the mask's bits map to them).
+            ncu = torch.cuda.get_device_properties(device).multi_processor_count
+            words = [[0] * ((ncu + 31) // 32) for _ in range(2)]
+            for cu in range(ncu):
+                words[1 if (cu // 8) % 4 < a.cu_split else 0][cu // 32] |= 1 << (cu % 32)
+            masked = [ca.MaskedStream(w) for w in words]
+            keep_streams.append(masked)
+            streams = tuple(torch.cuda.ExternalStream(m.handle, device=device) for m in masked)
         qlt.set_stream(streams[0].cuda_stream)
         caas.set_stream(streams[1].cuda_stream)
         for _, bfb in keep:
@@ -549,6 +563,8 @@ def main():
                        "ncells": ncells, "ntracers": nt, "cells_per_gpu": n,
                        "transport": transport, "rccl_nranks": world if (world > 1 and a.comm == "rccl") else 0,
                        "streams": 2 if streams else 1,
+                       "cu_split": ("CAAS on %d of every 4 groups of 8 CUs, QLT on the rest" % a.cu_split)
+                       if (streams and a.cu_split) else "none",
                        "caas_reducer": ("bfb_tree_allreduce, %d cells per leaf" % a.caas_bfb) if a.caas_bfb
                        else "own all-reduce"},
             "qlt": {"ms_per_run": 1e3 * t_qlt, "updates_per_s": ncells * nt / t_qlt},

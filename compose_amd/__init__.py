@@ -159,6 +159,8 @@ _SIGS = {
     "cedr_stream_synchronize": (C.c_int, [C.c_void_p]),
     "cedr_memcpy_h2d_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "cedr_memcpy_d2h_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "cedr_stream_create_cu_mask": (C.c_int, [C.POINTER(C.c_uint32), C.c_int32, C.POINTER(C.c_void_p)]),
+    "cedr_stream_destroy": (C.c_int, [C.c_void_p]),
     "cedr_device_synchronize": (C.c_int, []),
     # kernel level (layer K) entry points used directly by tests / bench
     "cedr_hip_level_up": (C.c_int, [_vp, C.c_int32, C.c_int32, _vp, C.c_int64, _vp, C.c_int, _vp]),
@@ -215,6 +217,28 @@ def _handle(h, what):
 
 def device_count():
     return lib().cedr_device_count()
+
+
+class MaskedStream:
+    """A HIP stream restricted to the compute units whose bit is set in `words` (32 per word;
+    cedr_stream_create_cu_mask). `.handle` is what set_stream() of a CDR takes."""
+
+    def __init__(self, words):
+        arr = (C.c_uint32 * len(words))(*[int(w) & 0xFFFFFFFF for w in words])
+        h = C.c_void_p()
+        _chk(lib().cedr_stream_create_cu_mask(arr, len(words), C.byref(h)), "cedr_stream_create_cu_mask")
+        self.handle = h.value
+
+    def close(self):
+        if self.handle:
+            lib().cedr_stream_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001 -- interpreter shutdown
+            pass
 
 
 def _ptr(x, need=None):

@@ -489,5 +489,10 @@ int cedr_memcpy_h2d_async (void* d, const void* s, size_t n, cedr_stream_t st) {
 int cedr_memcpy_d2h_async (void* d, const void* s, size_t n, cedr_stream_t st) {
   return static_cast<int>(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, st));
 }
+int cedr_stream_create_cu_mask (const uint32_t* mask, int32_t nwords, cedr_stream_t* st) {
+  if ( ! mask || nwords < 1 || ! st) return static_cast<int>(hipErrorInvalidValue);
+  return static_cast<int>(hipExtStreamCreateWithCUMask(st, static_cast<uint32_t>(nwords), mask));
+}
+int cedr_stream_destroy (cedr_stream_t st) { return static_cast<int>(hipStreamDestroy(st)); }
 
 }  // extern "C"

@@ -457,6 +457,12 @@ int cedr_device_synchronize(void);
 int cedr_stream_synchronize(cedr_stream_t stream);
 int cedr_memcpy_h2d_async(void* dst, const void* src, size_t bytes, cedr_stream_t stream);
 int cedr_memcpy_d2h_async(void* dst, const void* src, size_t bytes, cedr_stream_t stream);
+/* A stream whose kernels run only on the compute units whose bit is set in mask[0 .. nwords) (bit i of word w =
+ * compute unit 32w + i; hipExtStreamCreateWithCUMask). For a caller that runs two CDRs of a step side by
+ * side -- QLT::run's root->leaves sweep is bound by instruction issue, CAAS::run by HBM -- and wants each on
+ * its own share of the machine (set_stream of either CDR takes the handle). */
+int cedr_stream_create_cu_mask(const uint32_t* mask, int32_t nwords, cedr_stream_t* stream);
+int cedr_stream_destroy(cedr_stream_t stream);
 
 #ifdef __cplusplus
 }
