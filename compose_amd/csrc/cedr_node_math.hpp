@@ -21,7 +21,9 @@ enum : int { CONSERVE = 1, SHAPEPRESERVE = 2, CONSISTENT = 4, NONNEGATIVE = 8 };
 # define CEDR_NP_TRACE(code)
 #endif
 #if defined(__HIP_DEVICE_COMPILE__)
-# define CEDR_WAVE_ANY(p) (__ballot(p) != 0)
+// (the builtin takes the predicate as a lane mask; __ballot(int) would first turn it into 0 / 1 per lane and
+// compare that again: two vector instructions per use)
+# define CEDR_WAVE_ANY(p) (__builtin_amdgcn_ballot_w64(p) != 0)
 #else
 # define CEDR_WAVE_ANY(p) (p)
 #endif
@@ -270,14 +272,21 @@ void node_problem_mass_wave (const double p_lo, const double p_orig, const doubl
     const double al2 = hi1 - base;      // top:    x1 = hi1
     const double al3 = -(lo0 - base);   // left:   x0 = lo0
     const bool c01 = al0 > al1, c23 = al2 < al3;
-    const double a_lo = c01 ? al0 : al1, a_hi = c23 ? al2 : al3;    // the kept pair
-    const double a_min = c01 ? al1 : al0, a_max = c23 ? al3 : al2;  // the dropped pair
+    // the kept pair a_lo = c01 ? al0 : al1, a_hi = c23 ? al2 : al3 and the dropped pair a_min = c01 ? al1 : al0,
+    // a_max = c23 ? al3 : al2, as one max / min each instead of two selects: the same values (none is NaN); where
+    // the operands are +0 and -0 the sign may differ, which no use below can see (sums with base, squares,
+    // comparisons)
+    const double a_lo = fmax(al0, al1), a_hi = fmin(al2, al3);
+    const double a_min = fmin(al0, al1), a_max = fmax(al2, al3);
     // The scan drops exactly these two iff the FIRST minimum of the four is the dropped lower one
     // (a_min <= a_hi; a_min <= a_lo and a_hi <= a_max hold by construction) and the FIRST maximum is the
     // dropped upper one (a_max > a_lo, strictly: a tie would make index 0 or 1 the first maximum).
     // A node sitting exactly on a bound -- common: every box-edge solution puts a kid there -- has
     // a_lo == a_hi up to rounding and still passes.
-    general = general || ( ! done && ! (a_min <= a_hi && a_max > a_lo));
+    // (bitwise on purpose, here and for fixed1: lane masks combined by scalar and / or; `||` and `?:` between
+    // masks become selects on 0 / 1 vector registers)
+    const bool invalid = ! (a_min <= a_hi) | ! (a_max > a_lo);
+    general = general | ( ! done & invalid);
     double obj0, obj1;
     {
       const double t0 = base - a_lo, t1 = base + a_lo;
@@ -290,7 +299,7 @@ void node_problem_mass_wave (const double p_lo, const double p_orig, const doubl
       obj1 = r0.w*(d0*d0) + r1.w*(d1*d1);
     }
     const bool pick0 = obj0 <= obj1;
-    const bool fixed1 = pick0 ? c01 : c23;  // x1 sits on its bound, else x0 does
+    const bool fixed1 = (pick0 & c01) | ( ! pick0 & c23);  // x1 sits on its bound, else x0 does
     const double v_lo = c01 ? lo1 : hi0, v_hi = c23 ? hi1 : lo0;
     const double v = pick0 ? v_lo : v_hi;
     double other = Qm - v;
