@@ -236,6 +236,94 @@ void node_problem_mass_wave (const double p_lo, const double p_orig, const doubl
 #endif
   const bool outside = Qm < p_lo || Qm > p_hi;
   const bool quick = Qm == p_orig && or0 >= lo0 && or0 <= hi0 && or1 >= lo1 && or1 <= hi1;
+#ifndef CEDR_NP_WAVE_UNIFORM
+  // The three places where lanes part ways -- done already; the box-edge part; the general routine -- are
+  // ordinary divergent branches: lanes that do not need a part sit it out (exec mask) and the part is skipped
+  // when no lane needs it (s_cbranch_execz). Asking the wave first (a ballot) so that every lane runs the
+  // part costs two vector instructions per question and one more select level at the end.
+  x0 = or0; x1 = or1;
+  if ( ! outside & quick) {  // keeps its kids' masses
+    CEDR_NP_TRACE(1);
+    return;
+  }
+  // check_lu's corner exits (only with early_exit_on_tol = ! prefer)
+  bool exl = false, exh = false;
+  if ( ! prefer) {
+    const double ab = fmax(fmax(fabs(Qm), fabs(or0)), fabs(or1));
+    const double r_tol = 1e1*kEps*ab;
+    double r = -Qm;
+    r += lo0; r += lo1;
+    double r2 = -Qm;
+    r2 += hi0; r2 += hi1;
+    const bool out = ! (fabs(r) <= r_tol);
+    exl = out && r > 0;
+    exh = out && ! (r > 0) && ! (fabs(r2) <= r_tol) && r2 < 0;
+  }
+  // unconstrained optimum
+  const double qmass = r0.q + r1.q;
+  double dm = Qm;
+  dm -= or0; dm -= or1;
+  const double lambda = dm/qmass;
+  const double xa = or0 + lambda*r0.q;
+  const double xb = or1 + lambda*r1.q;
+  const bool inside = ! (xa < lo0 || xa > hi0) && ! (xb < lo1 || xb > hi1);
+  const bool done = exl | exh | inside;
+  // in the order in which node_problem_mass / qp_2d decide
+  double s0 = exl ? lo0 : (exh ? hi0 : xa);
+  double s1 = exl ? lo1 : (exh ? hi1 : xb);
+  bool general = outside;
+  if ( ! done & ! outside) {
+    const double base = 0.5*Qm;
+    const double al0 = lo1 - base;      // bottom: x1 = lo1
+    const double al1 = -(hi0 - base);   // right:  x0 = hi0
+    const double al2 = hi1 - base;      // top:    x1 = hi1
+    const double al3 = -(lo0 - base);   // left:   x0 = lo0
+    const bool c01 = al0 > al1, c23 = al2 < al3;
+    // the kept pair a_lo = c01 ? al0 : al1, a_hi = c23 ? al2 : al3 and the dropped pair a_min = c01 ? al1 : al0,
+    // a_max = c23 ? al3 : al2, as one max / min each instead of two selects: the same values (none is NaN); where
+    // the operands are +0 and -0 the sign may differ, which no use below can see (sums with base, squares,
+    // comparisons)
+    const double a_lo = fmax(al0, al1), a_hi = fmin(al2, al3);
+    const double a_min = fmin(al0, al1), a_max = fmax(al2, al3);
+    // The scan drops exactly these two iff the FIRST minimum of the four is the dropped lower one
+    // (a_min <= a_hi; a_min <= a_lo and a_hi <= a_max hold by construction) and the FIRST maximum is the
+    // dropped upper one (a_max > a_lo, strictly: a tie would make index 0 or 1 the first maximum).
+    // A node sitting exactly on a bound -- common: every box-edge solution puts a kid there -- has
+    // a_lo == a_hi up to rounding and still passes.
+    // (bitwise on purpose, here and for fixed1: lane masks combined by scalar and / or; `||` and `?:` between
+    // masks become selects on 0 / 1 vector registers)
+    general = ! (a_min <= a_hi) | ! (a_max > a_lo);
+    double obj0, obj1;
+    {
+      const double t0 = base - a_lo, t1 = base + a_lo;
+      const double d0 = or0 - t0, d1 = or1 - t1;
+      obj0 = r0.w*(d0*d0) + r1.w*(d1*d1);
+    }
+    {
+      const double t0 = base - a_hi, t1 = base + a_hi;
+      const double d0 = or0 - t0, d1 = or1 - t1;
+      obj1 = r0.w*(d0*d0) + r1.w*(d1*d1);
+    }
+    const bool pick0 = obj0 <= obj1;
+    const bool fixed1 = (pick0 & c01) | ( ! pick0 & c23);  // x1 sits on its bound, else x0 does
+    const double v_lo = c01 ? lo1 : hi0, v_hi = c23 ? hi1 : lo0;
+    const double v = pick0 ? v_lo : v_hi;
+    double other = Qm - v;
+    if ( ! prefer) {
+      const double lo_o = fixed1 ? lo0 : lo1, hi_o = fixed1 ? hi0 : hi1;
+      other = rmin(hi_o, rmax(lo_o, other));
+    }
+    s0 = fixed1 ? other : v;
+    s1 = fixed1 ? v : other;
+  }
+  if (general) {  // an infeasible node (adjusts bounds), a degenerate box: the reference's own control flow
+    CEDR_NP_TRACE(0);
+    node_problem_mass_cold(p_lo, p_orig, p_hi, Qm, r0, lo0, or0, hi0, r1, lo1, or1, hi1, s0, s1, prefer);
+  } else {
+    CEDR_NP_TRACE(exl || exh ? 2 : (inside ? 3 : 4));
+  }
+  x0 = s0; x1 = s1;
+#else
   if ( ! CEDR_WAVE_ANY(outside || ! quick)) {  // every lane keeps its kids' masses (unperturbed data)
     x0 = or0; x1 = or1;
     CEDR_NP_TRACE(1);
@@ -319,6 +407,7 @@ void node_problem_mass_wave (const double p_lo, const double p_orig, const doubl
   // in the order in which node_problem_mass / qp_2d decide
   x0 = quick ? or0 : (exl ? lo0 : (exh ? hi0 : (inside ? xa : e0)));
   x1 = quick ? or1 : (exl ? lo1 : (exh ? hi1 : (inside ? xb : e1)));
+#endif
 }
 
 // N independent node problems of one lane advanced in LOCKSTEP: the same operations on the same
