@@ -28,6 +28,19 @@ enum : int { CONSERVE = 1, SHAPEPRESERVE = 2, CONSISTENT = 4, NONNEGATIVE = 8 };
 # define CEDR_WAVE_ANY(p) (p)
 #endif
 
+// p ? a : b for three predicates that are each the result of ONE comparison. On the device the three lane masks
+// are combined by scalar instructions; written as `p ? a : b` (or with & and |, which the compiler turns back into
+// it) the choice is made on 0 / 1 values in vector registers: five vector instructions.
+__host__ __device__ __forceinline__ bool mask_select (const bool p, const bool a, const bool b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const unsigned long long mp = __builtin_amdgcn_ballot_w64(p);
+  return __builtin_amdgcn_inverse_ballot_w64((mp & __builtin_amdgcn_ballot_w64(a)) |
+                                             (~mp & __builtin_amdgcn_ballot_w64(b)));
+#else
+  return p ? a : b;
+#endif
+}
+
 // reference cedr_kokkos.hpp:136-139: comparisons, not fmin/fmax.
 __host__ __device__ __forceinline__ double rmin (double a, double b) { return a < b ? a : b; }
 __host__ __device__ __forceinline__ double rmax (double a, double b) { return a > b ? a : b; }
@@ -246,19 +259,6 @@ void node_problem_mass_wave (const double p_lo, const double p_orig, const doubl
     CEDR_NP_TRACE(1);
     return;
   }
-  // check_lu's corner exits (only with early_exit_on_tol = ! prefer)
-  bool exl = false, exh = false;
-  if ( ! prefer) {
-    const double ab = fmax(fmax(fabs(Qm), fabs(or0)), fabs(or1));
-    const double r_tol = 1e1*kEps*ab;
-    double r = -Qm;
-    r += lo0; r += lo1;
-    double r2 = -Qm;
-    r2 += hi0; r2 += hi1;
-    const bool out = ! (fabs(r) <= r_tol);
-    exl = out && r > 0;
-    exh = out && ! (r > 0) && ! (fabs(r2) <= r_tol) && r2 < 0;
-  }
   // unconstrained optimum
   const double qmass = r0.q + r1.q;
   double dm = Qm;
@@ -267,10 +267,31 @@ void node_problem_mass_wave (const double p_lo, const double p_orig, const doubl
   const double xa = or0 + lambda*r0.q;
   const double xb = or1 + lambda*r1.q;
   const bool inside = ! (xa < lo0 || xa > hi0) && ! (xb < lo1 || xb > hi1);
-  const bool done = exl | exh | inside;
-  // in the order in which node_problem_mass / qp_2d decide
-  double s0 = exl ? lo0 : (exh ? hi0 : xa);
-  double s1 = exl ? lo1 : (exh ? hi1 : xb);
+  double s0 = xa, s1 = xb;
+  // check_lu's corner exits (only with early_exit_on_tol = ! prefer), which qp_2d takes BEFORE it looks at the
+  // optimum. The two residuals are straight-line code (nearly every lane gets as far as the second); the exits
+  // themselves are rare and set their results in a branch (kept a branch by the empty asm: as selects every lane
+  // would pay eight instructions for them).
+  // (computed whatever `prefer` is and masked with it: under `if ( ! prefer)` the flag would live in a vector
+  // register as 0 / 1 across that branch)
+  const double ab = fmax(fmax(fabs(Qm), fabs(or0)), fabs(or1));
+  const double r_tol = 1e1*kEps*ab;
+  double r = -Qm;
+  r += lo0; r += lo1;
+  double r2 = -Qm;
+  r2 += hi0; r2 += hi1;
+  const bool out = ! (fabs(r) <= r_tol);
+  const bool exl = out & (r > 0);
+  const bool exh = out & ! (r > 0) & ! (fabs(r2) <= r_tol) & (r2 < 0);
+  const bool corner = ! prefer & (exl | exh);
+  if (corner) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("");
+#endif
+    s0 = exl ? lo0 : hi0;
+    s1 = exl ? lo1 : hi1;
+  }
+  const bool done = inside | corner;
   bool general = outside;
   if ( ! done & ! outside) {
     const double base = 0.5*Qm;
@@ -305,7 +326,7 @@ void node_problem_mass_wave (const double p_lo, const double p_orig, const doubl
       obj1 = r0.w*(d0*d0) + r1.w*(d1*d1);
     }
     const bool pick0 = obj0 <= obj1;
-    const bool fixed1 = (pick0 & c01) | ( ! pick0 & c23);  // x1 sits on its bound, else x0 does
+    const bool fixed1 = mask_select(pick0, c01, c23);  // x1 sits on its bound, else x0 does
     const double v_lo = c01 ? lo1 : hi0, v_hi = c23 ? hi1 : lo0;
     const double v = pick0 ? v_lo : v_hi;
     double other = Qm - v;
@@ -320,7 +341,7 @@ void node_problem_mass_wave (const double p_lo, const double p_orig, const doubl
     CEDR_NP_TRACE(0);
     node_problem_mass_cold(p_lo, p_orig, p_hi, Qm, r0, lo0, or0, hi0, r1, lo1, or1, hi1, s0, s1, prefer);
   } else {
-    CEDR_NP_TRACE(exl || exh ? 2 : (inside ? 3 : 4));
+    CEDR_NP_TRACE(corner ? 2 : (inside ? 3 : 4));
   }
   x0 = s0; x1 = s1;
 #else
