@@ -1121,10 +1121,10 @@ void qlt_down_sp_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st,
   const cedr_hip_tile tile = st.tiles[tix];
   uint32_t* const kidsL = reinterpret_cast<uint32_t*>(lds);
   int32_t* const lvlL = reinterpret_cast<int32_t*>(kidsL + st.max_nint);
-  double* const rho = lds + (st.max_nint + 1);
-  double* const rw = rho + MN;
-  double* const rq = rw + MN;
-  double* const cellrho = rq + MN;            // [kCellRho][kWave]
+  // density records {rhom, 1/rhom, 1/(1/rhom)} of the tile's nodes, three doubles apart: one address per kid in the
+  // node problems of the LDS levels (and 3 x node mod 16 is a permutation of the bank pairs)
+  double* const rho3 = lds + (st.max_nint + 1);
+  double* const cellrho = rho3 + 3*MN;        // [kCellRho][kWave]
   double* const recs = cellrho + kCellRho*kWave;
   // after the records: row tables (ROWS), then the tracers' l2r field / r2l row and the outputs' node ids
   const double** const inL = reinterpret_cast<const double**>(recs + static_cast<size_t>(TT)*pitch);
@@ -1190,7 +1190,7 @@ void qlt_down_sp_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st,
     cellrho[(3*wave + 1)*kWave + lane] = w;
     cellrho[(3*wave + 2)*kWave + lane] = 1.0/w;
     // (a,b)+c and a+(b,c) are the same sum: fp addition commutes
-    if (wave == 3 && lane < nleaf) rho[lane] = m.shape <= 0 ? rh[0] : (m.shape == 1 ? t : t + rh[2]);
+    if (wave == 3 && lane < nleaf) rho3[3*lane] = m.shape <= 0 ? rh[0] : (m.shape == 1 ? t : t + rh[2]);
   }
   stage_tile_meta(st, tile, kidsL, lvlL);
   __syncthreads();
@@ -1198,14 +1198,14 @@ void qlt_down_sp_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st,
     const int a = lvlL[lv], b = lvlL[lv+1];
     for (int j = a + threadIdx.x; j < b; j += kBlock) {
       const uint32_t kk = kidsL[j];
-      rho[nleaf + j] = rho[kk & 0xffff] + rho[kk >> 16];
+      rho3[3*(nleaf + j)] = rho3[3*(kk & 0xffff)] + rho3[3*(kk >> 16)];
     }
     __syncthreads();
   }
   for (int i = threadIdx.x; i < nleaf + tile.nint; i += kBlock) {
-    const double w = 1.0/rho[i];
-    rw[i] = w;
-    rq[i] = 1.0/w;
+    const double w = 1.0/rho3[3*i];
+    rho3[3*i + 1] = w;
+    rho3[3*i + 2] = 1.0/w;
   }
   double* const R = recs + tt*pitch;          // this thread's record row in the LDS phases
 
@@ -1267,7 +1267,7 @@ void qlt_down_sp_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st,
         const int j = a + (q >> Log2<TT>::value);
         const uint32_t kk = kidsL[j];
         const int c0 = kk & 0xffff, c1 = kk >> 16, me = nleaf + j;
-        const KidRho r0{rho[c0], rw[c0], rq[c0]}, r1{rho[c1], rw[c1], rq[c1]};
+        const KidRho r0{rho3[3*c0], rho3[3*c0 + 1], rho3[3*c0 + 2]}, r1{rho3[3*c1], rho3[3*c1 + 1], rho3[3*c1 + 2]};
         const double* P = R + kRS*me;
         double* K0 = R + kRS*c0;
         double* K1 = R + kRS*c1;
@@ -1286,16 +1286,15 @@ void qlt_down_sp_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st,
     for (int s = 0; s < TW; ++s) {
       const int biw = c*TT + wave + kNW*s;
       if (biw >= nt || lane >= nleaf) continue;
-      double T[3], RR[3];  // inner pair t and micro root: {lo, orig, hi} sums, re-formed
+      double T[3];  // inner pair t: {lo, orig, hi} sums, re-formed
 #pragma unroll
-      for (int f = 0; f < 3; ++f) {
-        T[f] = cur[s][0][f] + cur[s][1][f];
-        RR[f] = m.shape <= 0 ? cur[s][0][f] : (m.shape == 1 ? T[f] : T[f] + cur[s][2][f]);
-      }
+      for (int f = 0; f < 3; ++f) T[f] = cur[s][0][f] + cur[s][1][f];
       const double Xr = recs[(wave + kNW*s)*pitch + kRS*lane + 3];
       double Xt = Xr, Xu = Xr, Xv = 0, Xp = 0;
       const KidRho kt{cellrho[9*kWave + lane], cellrho[10*kWave + lane], cellrho[11*kWave + lane]};
       if ((any2 && m.shape == 2) || (any3 && m.shape == 3)) {
+        // the micro root's sums, re-formed: three cells here, so t + p whatever the shape (no selects)
+        const double RR[3] = {T[0] + cur[s][2][0], T[1] + cur[s][2][1], T[2] + cur[s][2][2]};
         const KidRho kp{cellrho[6*kWave + lane], cellrho[7*kWave + lane], cellrho[8*kWave + lane]};
         if (any2 && m.shape == 2)
           node_problem_sel< ! ROWS>(RR[0], RR[1], RR[2], Xr, kt, T[0], T[1], T[2],

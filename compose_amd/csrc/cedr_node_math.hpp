@@ -41,6 +41,19 @@ __host__ __device__ __forceinline__ bool mask_select (const bool p, const bool a
 #endif
 }
 
+// max(|a|, |b|, |c|) of three numbers that are not NaN. -DCEDR_ASM_ABSMAX: two v_max_f64 with |.| source
+// modifiers (hipcc's fmax(fabs(x), ...) quiets every operand first: three more v_max_f64 x, x, x).
+__host__ __device__ __forceinline__ double absmax3 (const double a, const double b, const double c) {
+#if defined(__HIP_DEVICE_COMPILE__) && defined(CEDR_ASM_ABSMAX)
+  double t, r;
+  asm("v_max_f64 %0, |%1|, |%2|" : "=v"(t) : "v"(a), "v"(b));
+  asm("v_max_f64 %0, %1, |%2|" : "=v"(r) : "v"(t), "v"(c));
+  return r;
+#else
+  return fmax(fmax(fabs(a), fabs(b)), fabs(c));
+#endif
+}
+
 // reference cedr_kokkos.hpp:136-139: comparisons, not fmin/fmax.
 __host__ __device__ __forceinline__ double rmin (double a, double b) { return a < b ? a : b; }
 __host__ __device__ __forceinline__ double rmax (double a, double b) { return a > b ? a : b; }
@@ -274,7 +287,7 @@ void node_problem_mass_wave (const double p_lo, const double p_orig, const doubl
   // would pay eight instructions for them).
   // (computed whatever `prefer` is and masked with it: under `if ( ! prefer)` the flag would live in a vector
   // register as 0 / 1 across that branch)
-  const double ab = fmax(fmax(fabs(Qm), fabs(or0)), fabs(or1));
+  const double ab = absmax3(Qm, or0, or1);
   const double r_tol = 1e1*kEps*ab;
   double r = -Qm;
   r += lo0; r += lo1;
