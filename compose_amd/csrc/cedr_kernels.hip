@@ -1087,9 +1087,9 @@ void qlt_down_micro_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st
 # define CEDR_DOWN_SP_WAVES1 5  // ... and the 1-tracer-per-wave build
 #endif
 
-// The node problem of the shape-preserving root->leaves kernel: the straight-line form, except in the zero-copy
-// (ROWS) build, which has no register to spare for it (8 spilled VGPRs in its loop with it, none without:
-// QLT::run on bound arrays 1.15 against 1.02 ms).
+// The node problem of the shape-preserving root->leaves kernel: the form written for how a wave executes it
+// (node_problem_mass_wave), in the zero-copy (ROWS) build too since that form got by with divergent branches
+// (94 VGPRs, no spills; with the ballot form that build spilled 8 VGPRs in its loop). <false> = the branchy routine.
 
 template <bool WAVE>
 __device__ __forceinline__
@@ -1272,7 +1272,7 @@ void qlt_down_sp_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st,
         double* K0 = R + kRS*c0;
         double* K1 = R + kRS*c1;
         double x0, x1;
-        node_problem_sel< ! ROWS>(P[0], P[1], P[2], P[3], r0, K0[0], K0[1], K0[2], r1, K1[0], K1[1], K1[2],
+        node_problem_sel<true>(P[0], P[1], P[2], P[3], r0, K0[0], K0[1], K0[2], r1, K1[0], K1[1], K1[2],
                           x0, x1, prefer);
         K0[3] = x0;
         K1[3] = x1;
@@ -1297,16 +1297,16 @@ void qlt_down_sp_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st,
         const double RR[3] = {T[0] + cur[s][2][0], T[1] + cur[s][2][1], T[2] + cur[s][2][2]};
         const KidRho kp{cellrho[6*kWave + lane], cellrho[7*kWave + lane], cellrho[8*kWave + lane]};
         if (any2 && m.shape == 2)
-          node_problem_sel< ! ROWS>(RR[0], RR[1], RR[2], Xr, kt, T[0], T[1], T[2],
+          node_problem_sel<true>(RR[0], RR[1], RR[2], Xr, kt, T[0], T[1], T[2],
                             kp, cur[s][2][0], cur[s][2][1], cur[s][2][2], Xt, Xp, prefer);
         if (any3 && m.shape == 3)
-          node_problem_sel< ! ROWS>(RR[0], RR[1], RR[2], Xr, kp, cur[s][2][0], cur[s][2][1], cur[s][2][2],
+          node_problem_sel<true>(RR[0], RR[1], RR[2], Xr, kp, cur[s][2][0], cur[s][2][1], cur[s][2][2],
                             kt, T[0], T[1], T[2], Xp, Xt, prefer);
       }
       if (m.shape >= 1) {
         const KidRho ku{cellrho[0*kWave + lane], cellrho[1*kWave + lane], cellrho[2*kWave + lane]};
         const KidRho kv{cellrho[3*kWave + lane], cellrho[4*kWave + lane], cellrho[5*kWave + lane]};
-        node_problem_sel< ! ROWS>(T[0], T[1], T[2], Xt, ku, cur[s][0][0], cur[s][0][1], cur[s][0][2],
+        node_problem_sel<true>(T[0], T[1], T[2], Xt, ku, cur[s][0][0], cur[s][0][1], cur[s][0][2],
                           kv, cur[s][1][0], cur[s][1][1], cur[s][1][2], Xu, Xv, prefer);
       }
       double* __restrict__ const orow = (ROWS ? outL[biw] : r2l + static_cast<size_t>(r2lL[biw])*S) + tile.in0;
