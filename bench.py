@@ -485,10 +485,17 @@ def main():
                                 "profiles/r03_kernel_stats_by_grid.csv splits the same trace by kernel instantiation "
                                 "and launch grid (tools/kernel_stats_by_grid.py)")
         if dom["kernel"] == "qlt_down_kernel":
-            roofline["bound_note"] = ("reported against the HBM roofline, the metric's roofline; with cache-resident "
-                                      "inputs this kernel is as slow (profiles/r02_down_experiments.md 1): its limiter "
-                                      "is the dependent chain of node problems per chunk at the occupancy 96 VGPRs allow "
-                                      "(profiles/r03_experiments.md 2-3)")
+            roofline["bound_note"] = ("reported against the HBM roofline, the metric's roofline. Round 3 took a third of "
+                                      "the node problems' vector instructions out (predicates kept as scalar lane masks: "
+                                      "0.445 -> 0.405 ms); further cuts buy nothing, a sixth wave per SIMD needs 80 VGPRs "
+                                      "(spills: +20 %): the kernel sits on its streaming skeleton at five waves per SIMD "
+                                      "(profiles/r03_experiments.md 11)")
+        elif dom["kernel"] == "tree_up_kernel":
+            roofline["bound_note"] = ("the reads stream at the copy rate (0.31 ms); the gap is the 1.3 M isolated 128-byte "
+                                      "output lines written between them (profiles/r02_down_experiments.md 2). This kernel "
+                                      "takes 0.383-0.387 ms in some processes and 0.40-0.43 ms in others on the same box "
+                                      "with the same binary (decided at process start, profiles/r03_experiments.md 11); "
+                                      "whichever of the two first-stage sweeps is slower in this process is reported here")
 
     # Pack / unpack either side of run() (reported apart from `value`).
     def timed_sync(fn, reps=5):
