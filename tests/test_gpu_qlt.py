@@ -256,3 +256,23 @@ def test_sweep_down_event_orders_a_second_stream(gpu, oracle):
     ca.synchronize()
     assert np.array_equal(qo.numpy(v.Qm.shape), want)
     assert common.rel_per_tracer(co.numpy(cv.Qm.shape), cwant).max() <= 1e-13
+
+
+def test_qlt_on_a_cu_masked_stream(gpu, oracle):
+    """cedr_stream_create_cu_mask: a stream restricted to half of the compute units (every other group of eight).
+    QLT::run on it gives the same bits; an empty argument list is refused."""
+    ca = gpu
+    trs = R.tracers_vector()
+    types = [t.problem_type for t in trs]
+    ncells = 3000
+    v = R.make_values(trs, ncells, seed=77)
+    want = common.run_oracle_qlt(oracle, (False, False), ncells, 1, types, v)
+    q = common.make_hip_qlt(ca, ca.Tree.make_1d(ncells), ncells, types)
+    ms = ca.MaskedStream([0x00FF00FF] * 8)
+    q.set_stream(ms.handle)
+    got = common.run_hip_qlt(ca, q, v)
+    assert np.array_equal(got, want)
+    q.set_stream(0)
+    ms.close()
+    with pytest.raises(ca.CedrError):
+        ca.MaskedStream([])
