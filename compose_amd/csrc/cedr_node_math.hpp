@@ -235,12 +235,17 @@ void node_problem_mass_cold (const double p_lo, const double p_orig, const doubl
 // wave almost never agree on which way node_problem_mass branches, so the wave runs both sides of
 // nearly every `if`, and every divergent branch costs a saveexec / branch / restore sequence and a
 // fetch bubble on top. Here the COMMON case -- the node's mass inside its bounds, which is every node
-// of a feasible problem -- is straight-line code: all candidate results (keep the kids' masses; the
-// corner exits of check_lu; the unconstrained optimum; the better of the two box-edge intersections)
-// are computed unconditionally and picked by selects. Two wave-uniform branches remain: past the
-// box-edge part when no lane needs it (real data: most nodes), and to node_problem_mass itself, for the
-// whole wave, when ANY lane is in a case the straight-line code does not cover (an infeasible node,
-// which adjusts bounds; a degenerate box whose edge intersections do not separate).
+// of a feasible problem -- is straight-line code: the unconstrained optimum and the corner exits'
+// residuals are computed unconditionally. Lanes part ways in three places only, by ordinary divergent
+// branches that are skipped when no lane takes them: lanes that keep their kids' masses are done; the
+// box-edge part runs for the lanes whose optimum is outside the box; and the reference's own control
+// flow (node_problem_mass) runs for the lanes in a case the straight-line code does not cover (an
+// infeasible node, which adjusts bounds; a degenerate box whose edge intersections do not separate).
+// Predicates are combined with & and | on purpose and a select between lane masks goes through
+// mask_select: this compiler keeps `a && b`, `p ? a : b` and ballots of combined predicates as 0 / 1
+// values in vector registers (profiles/r03_experiments.md 11).
+// (-DCEDR_NP_WAVE_UNIFORM: the earlier form, which asked the wave before each part -- a ballot -- and
+// ran the part for all lanes.)
 //
 // The box-edge part replaces qp_edges' twelve comparisons by four, using what the reference's scan
 // (cedr_local_inl.hpp:121-147: first minimum and first maximum of the four alphas, the two remaining
