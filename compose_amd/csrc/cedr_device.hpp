@@ -21,6 +21,7 @@ public:
   Buffer& operator= (const Buffer&) = delete;
   ~Buffer () { release(); }
   void release () { if (p_) (void) hipFree(p_); p_ = nullptr; n_ = 0; }
+  void swap (Buffer& o) { T* const p = p_; p_ = o.p_; o.p_ = p; const size_t n = n_; n_ = o.n_; o.n_ = n; }
   void alloc (size_t n) {
     release();
     n_ = n;

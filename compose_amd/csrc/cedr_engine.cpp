@@ -188,6 +188,43 @@ void TreeEngine::up_local (int32_t nfields, const uint8_t* op_dev, double* data,
   if (local_.empty() && first_ev_) cedr_throw_if(hipEventRecord(first_ev_, stream) != hipSuccess, "hipEventRecord failed");
 }
 
+namespace {
+// Best of three timed launches after a warm-up one; negative on any failure.
+template <typename Launch>
+float best_ms (hipStream_t stream, const Launch& launch) {
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (hipEventCreate(&e0) != hipSuccess) return -1;
+  if (hipEventCreate(&e1) != hipSuccess) { (void) hipEventDestroy(e0); return -1; }
+  float best = -1;
+  for (int rep = 0; rep < 4; ++rep) {
+    bool ok = hipEventRecord(e0, stream) == hipSuccess;
+    ok = ok && launch() == 0;
+    ok = ok && hipEventRecord(e1, stream) == hipSuccess && hipEventSynchronize(e1) == hipSuccess;
+    float ms = 0;
+    if ( ! ok || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) { best = -1; break; }
+    if (rep > 0 && (best < 0 || ms < best)) best = ms;
+  }
+  (void) hipEventDestroy(e0);
+  (void) hipEventDestroy(e1);
+  return best;
+}
+const int32_t kMinTilesToTime = 2048;  // below that a stage takes a few tens of microseconds
+}  // namespace
+
+float TreeEngine::time_first_stage (int32_t nfields, const uint8_t* op_dev, double* data, hipStream_t stream) {
+  if ( ! uploaded_ || local_.empty() || plan_.local[0].top || local_[0]->h.ntiles < kMinTilesToTime) return -1;
+  return best_ms(stream, [&] {
+    return cedr_hip_tree_up_rows_sums(&local_[0]->h, nfields, op_dev, stride_, data, nullptr, plan_.nlcl, 0,
+                                      all_sums_, stream);
+  });
+}
+
+float TreeEngine::time_first_stage_down (const cedr_hip_qlt_layout* lay, double* l2r, double* r2l,
+                                         hipStream_t stream) {
+  if ( ! uploaded_ || local_.empty() || plan_.local[0].top || local_[0]->h.ntiles < kMinTilesToTime) return -1;
+  return best_ms(stream, [&] { return cedr_hip_qlt_down(lay, &local_[0]->h, l2r, r2l, stream); });
+}
+
 void TreeEngine::up (int32_t nfields, const uint8_t* op_dev, double* data, bool zero_init,
                      hipStream_t stream, const double* const* in_rows, bool skip_top, double* root_out) {
   const bool xch = ! plan_.level_mode && ! top_.empty();

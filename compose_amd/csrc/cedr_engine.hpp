@@ -55,6 +55,14 @@ public:
           hipStream_t stream, const double* const* in_rows = nullptr, bool skip_top = false,
           double* root_out = nullptr);
   bool takes_root_out () const { return has_top() && plan_.nranks == 1 && ! plan_.level_mode; }
+  // Milliseconds the first local leaves->root stage takes over 'data' (best of three launches; it only sums, and
+  // writes the stage's tile-output slots of data), or a negative value when that stage is too small for the answer
+  // to matter. For owners that allocate 'data' themselves: the same kernel over the same bytes runs up to 12 %
+  // faster or slower depending on which device memory the allocation got (profiles/r03_experiments.md 12), so an
+  // owner may try a few allocations and keep the best.
+  float time_first_stage(int32_t nfields, const uint8_t* op_dev, double* data, hipStream_t stream);
+  // The same for the first local root->leaves stage of QLT (cedr_hip_qlt_down over l2r / r2l).
+  float time_first_stage_down(const cedr_hip_qlt_layout* lay, double* l2r, double* r2l, hipStream_t stream);
   // The fused top tile (plan::Stage::top): the last local stage, swept by the tracer-parallel top
   // kernels in one launch per direction.
   // Recorded (if set) on the sweep's stream right after the first local leaves->root stage of every up().

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 
 #include "../../include/cedr_hip.h"
@@ -249,19 +250,6 @@ void QLTHip::finish_setup () {
     o.trcr2bl2r = d.trcr2bl2r.data();
     o.trcr2br2l = d.trcr2br2l.data();
   }
-  if ( ! d.inited) {
-    // Own allocation: only what this build's layout touches (fields x stride). That is about
-    // half of the reference's figure, which get_buffers_sizes reports for callers who bring
-    // their own memory: internal tree nodes other than tile outputs never reach HBM here.
-    const size_t stride = static_cast<size_t>(eng_->stride());
-    d.l2r_own.alloc_zero(md_.prob2bl2r[MetaData::nprobtypes]*stride);
-    d.r2l_own.alloc_zero(md_.prob2br2l[MetaData::nprobtypes]*stride);
-    d.l2r = d.l2r_own.data();
-    d.r2l = d.r2l_own.data();
-    d.inited = true;
-  }
-  o.l2r_data = d.l2r;
-  o.r2l_data = d.r2l;
   d.lay.nt = get_num_tracers();
   d.lay.l2rndps = md_.prob2bl2r[MetaData::nprobtypes];
   d.lay.r2lndps = md_.prob2br2l[MetaData::nprobtypes];
@@ -277,6 +265,56 @@ void QLTHip::finish_setup () {
     for (const Int pt : md_.trcr2prob) if ( ! (pt & ProblemType::shapepreserve)) all_sp = false;
     if (all_sp) d.lay.flags |= CEDR_QLT_ALL_SHAPEPRESERVE;
   }
+  if ( ! d.inited) {
+    // Own allocation: only what this build's layout touches (fields x stride). That is about
+    // half of the reference's figure, which get_buffers_sizes reports for callers who bring
+    // their own memory: internal tree nodes other than tile outputs never reach HBM here.
+    const size_t stride = static_cast<size_t>(eng_->stride());
+    const size_t nl2r = md_.prob2bl2r[MetaData::nprobtypes]*stride;
+    d.r2l_own.alloc_zero(md_.prob2br2l[MetaData::nprobtypes]*stride);
+    d.l2r_own.alloc_zero(nl2r);
+    // Which device memory an allocation gets decides how fast the first-stage sweeps stream it (the leaves->root
+    // kernel 0.385-0.44 ms over the same 1.9 GB at 1.5M cells x 40 tracers, the root->leaves kernel +-3 %, not
+    // always the same way; nothing in the virtual address tells; profiles/r03_experiments.md 12). With a first
+    // stage big enough for it to matter a few more allocations of the l2r buffer are tried -- the earlier ones
+    // kept meanwhile, so that each gets other memory -- and the one over which the two first-stage sweeps together
+    // run fastest is kept (on zeros: the sweeps' memory traffic does not depend on the data).
+    // CEDR_HIP_PLACE_TRIES (default 4; 1 = take the first). Callers who bring their own memory are not affected.
+    const char* const tv = std::getenv("CEDR_HIP_PLACE_TRIES");
+    const int tries = tv ? std::atoi(tv) : 4;
+    if (tries > 1) {
+      const int32_t nf = md_.prob2bl2r[MetaData::nprobtypes];
+      const auto score = [&] (Real* l2r) -> float {
+        const float up = eng_->time_first_stage(nf, d.l2r_op.data(), l2r, d.stream);
+        if (up <= 0) return -1;
+        const float down = eng_->time_first_stage_down(&d.lay, l2r, d.r2l_own.data(), d.stream);
+        return down > 0 ? up + down : -1;
+      };
+      float best = score(d.l2r_own.data());
+      const bool verbose = std::getenv("CEDR_HIP_PLACE_VERBOSE") != nullptr;
+      if (verbose) std::fprintf(stderr, "cedr: l2r placement try 0: %.4f ms\n", best);
+      if (best > 0) {
+        std::vector<std::unique_ptr<dev::Buffer<Real> > > parked;
+        for (int t = 1; t < tries; ++t) {
+          std::unique_ptr<dev::Buffer<Real> > c(new dev::Buffer<Real>());
+          try { c->alloc_zero(nl2r); }
+          catch (const std::exception&) { (void) hipGetLastError(); break; }  // out of memory: keep what we have
+          const float ms = score(c->data());
+          if (verbose) std::fprintf(stderr, "cedr: l2r placement try %d: %.4f ms (best so far %.4f)\n", t, ms, best);
+          if (ms > 0 && ms < 0.995f*best) { best = ms; c->swap(d.l2r_own); }
+          parked.push_back(std::move(c));
+        }
+        parked.clear();
+        cedr_hip_check(hipMemset(d.l2r_own.data(), 0, nl2r*sizeof(Real)));  // the timed sweeps wrote into both
+        cedr_hip_check(hipMemset(d.r2l_own.data(), 0, d.r2l_own.size()*sizeof(Real)));
+      }
+    }
+    d.l2r = d.l2r_own.data();
+    d.r2l = d.r2l_own.data();
+    d.inited = true;
+  }
+  o.l2r_data = d.l2r;
+  o.r2l_data = d.r2l;
 }
 
 int QLTHip::get_problem_type (const Int& tracer_idx) const {

@@ -263,3 +263,21 @@ def test_config_C_sharded_8_ways(gpu, oracle):
     cw, _ = common.run_oracle_caas(oracle, [n], [CST] * len(sub), vs)
     for got in (c8, b8):
         assert common.rel_per_tracer(got[sub].cpu().numpy(), cw).max() <= 1e-13
+
+
+def test_qlt_placement_tries_do_not_change_results(gpu, monkeypatch):
+    """QLT::finish_setup tries several allocations of its l2r buffer (CEDR_HIP_PLACE_TRIES) and times the first-stage
+    sweeps over them; the buffers it ends up with are clean and the results are the same bits as with one try."""
+    ca = gpu
+    ncells, nt = 400000, 3  # > 2048 first-stage tiles: enough for the tries to run
+    trs = R.tracers_vector()[:nt]
+    types = [t.problem_type for t in trs]
+    v = R.make_values(trs, ncells, seed=12)
+    outs = []
+    for tries in ("1", "3"):
+        monkeypatch.setenv("CEDR_HIP_PLACE_TRIES", tries)
+        q = common.make_hip_qlt(ca, ca.Tree.make_1d(ncells), ncells, types)
+        assert len(q.plan()["local"][0]["tiles"]) >= 2048
+        outs.append(common.run_hip_qlt(ca, q, v))
+    assert np.array_equal(outs[0], outs[1])
+    assert R.check(trs, v, outs[1], False, verbose=False)[0] == 0
