@@ -278,35 +278,43 @@ void QLTHip::finish_setup () {
     // always the same way; nothing in the virtual address tells; profiles/r03_experiments.md 12). With a first
     // stage big enough for it to matter a few more allocations of the l2r buffer are tried -- the earlier ones
     // kept meanwhile, so that each gets other memory -- and the one over which the two first-stage sweeps together
-    // run fastest is kept (on zeros: the sweeps' memory traffic does not depend on the data).
+    // run fastest is kept (on zeros: the sweeps' memory traffic does not depend on the data); then the same for the
+    // r2l buffer with the root->leaves sweep.
     // CEDR_HIP_PLACE_TRIES (default 4; 1 = take the first). Callers who bring their own memory are not affected.
     const char* const tv = std::getenv("CEDR_HIP_PLACE_TRIES");
     const int tries = tv ? std::atoi(tv) : 4;
     if (tries > 1) {
       const int32_t nf = md_.prob2bl2r[MetaData::nprobtypes];
-      const auto score = [&] (Real* l2r) -> float {
-        const float up = eng_->time_first_stage(nf, d.l2r_op.data(), l2r, d.stream);
-        if (up <= 0) return -1;
-        const float down = eng_->time_first_stage_down(&d.lay, l2r, d.r2l_own.data(), d.stream);
+      const size_t nr2l = d.r2l_own.size();
+      const bool verbose = std::getenv("CEDR_HIP_PLACE_VERBOSE") != nullptr;
+      // both first-stage sweeps for an l2r candidate; the root->leaves one alone for an r2l candidate
+      const auto score = [&] (Real* l2r, Real* r2l, const bool both) -> float {
+        const float up = both ? eng_->time_first_stage(nf, d.l2r_op.data(), l2r, d.stream) : 0.0f;
+        if (both && up <= 0) return -1;
+        const float down = eng_->time_first_stage_down(&d.lay, l2r, r2l, d.stream);
         return down > 0 ? up + down : -1;
       };
-      float best = score(d.l2r_own.data());
-      const bool verbose = std::getenv("CEDR_HIP_PLACE_VERBOSE") != nullptr;
-      if (verbose) std::fprintf(stderr, "cedr: l2r placement try 0: %.4f ms\n", best);
-      if (best > 0) {
+      const auto pick = [&] (dev::Buffer<Real>& own, const size_t n, const bool is_l2r) -> bool {
+        float best = is_l2r ? score(own.data(), d.r2l_own.data(), true) : score(d.l2r_own.data(), own.data(), false);
+        if (verbose) std::fprintf(stderr, "cedr: %s placement try 0: %.4f ms\n", is_l2r ? "l2r" : "r2l", best);
+        if (best <= 0) return false;
         std::vector<std::unique_ptr<dev::Buffer<Real> > > parked;
         for (int t = 1; t < tries; ++t) {
           std::unique_ptr<dev::Buffer<Real> > c(new dev::Buffer<Real>());
-          try { c->alloc_zero(nl2r); }
+          try { c->alloc_zero(n); }
           catch (const std::exception&) { (void) hipGetLastError(); break; }  // out of memory: keep what we have
-          const float ms = score(c->data());
-          if (verbose) std::fprintf(stderr, "cedr: l2r placement try %d: %.4f ms (best so far %.4f)\n", t, ms, best);
-          if (ms > 0 && ms < 0.995f*best) { best = ms; c->swap(d.l2r_own); }
+          const float ms = is_l2r ? score(c->data(), d.r2l_own.data(), true) : score(d.l2r_own.data(), c->data(), false);
+          if (verbose) std::fprintf(stderr, "cedr: %s placement try %d: %.4f ms (best so far %.4f)\n",
+                                    is_l2r ? "l2r" : "r2l", t, ms, best);
+          if (ms > 0 && ms < 0.995f*best) { best = ms; c->swap(own); }
           parked.push_back(std::move(c));
         }
-        parked.clear();
+        return true;
+      };
+      if (pick(d.l2r_own, nl2r, true)) {
+        pick(d.r2l_own, nr2l, false);
         cedr_hip_check(hipMemset(d.l2r_own.data(), 0, nl2r*sizeof(Real)));  // the timed sweeps wrote into both
-        cedr_hip_check(hipMemset(d.r2l_own.data(), 0, d.r2l_own.size()*sizeof(Real)));
+        cedr_hip_check(hipMemset(d.r2l_own.data(), 0, nr2l*sizeof(Real)));
       }
     }
     d.l2r = d.l2r_own.data();

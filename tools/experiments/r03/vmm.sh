@@ -4,7 +4,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd "$R"
 mkdir -p gpurun_out/r03env
 for pass in 1 2 3 4; do
-for cfg in "0 1" "1 1" "0 4" "1 4"; do
+for cfg in "0 1" "0 4"; do
   set -- $cfg
   CEDR_HIP_PLACE_VERBOSE=1 CEDR_HIP_VMM=$1 CEDR_HIP_PLACE_TRIES=$2 timeout -k 10 300 python3 bench.py --steps 40 --warmup 5 --no-cpu-baseline --serial --check > gpurun_out/r03env/vm.json 2> gpurun_out/r03env/vm.err || { tail -3 gpurun_out/r03env/vm.err; continue; }
   python3 - "$cfg" "$(grep -c 'vmm 1' gpurun_out/r03env/vm.err)" <<'PY'
