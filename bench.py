@@ -424,6 +424,10 @@ def main():
         caas.set_stream(None)
         for _, bfb in keep:
             bfb.set_stream(None)
+    # The same K steps back to back on ONE stream (the shape of rounds 1-2, of the CPU baseline and of the
+    # roofline leg below), reported next to the two-stream `value` at every N: the two programs differ only in
+    # the overlap, so a regression of the cross-stream ordering over real RCCL shows up as a difference here.
+    t_serial = timed(step) if streams else dt / a.steps
     ca.profile_start()
     for _ in range(a.steps):
         step()
@@ -574,6 +578,8 @@ def main():
                        if (streams and a.cu_split) else "none",
                        "caas_reducer": ("bfb_tree_allreduce, %d cells per leaf" % a.caas_bfb) if a.caas_bfb
                        else "own all-reduce"},
+            "serial": {"ms_per_step": 1e3 * t_serial, "value": 2.0 * ncells * nt / t_serial,
+                       "note": "the same steps with QLT::run and CAAS::run back to back on one stream"},
             "qlt": {"ms_per_run": 1e3 * t_qlt, "updates_per_s": ncells * nt / t_qlt},
             "caas": {"ms_per_run": 1e3 * t_caas, "updates_per_s": ncells * nt / t_caas},
             "pack_unpack": pack, "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu,

@@ -42,10 +42,7 @@ void BfbTreeAllReducerHip::init (const mpi::Parallel::Ptr& p, const tree::FlatTr
   nlocal_ = static_cast<Int>(ns_->levels[0].nodes.size());
   nfield_ = nfield;
   plan::Options popt;
-  if (const char* e = std::getenv("CEDR_HIP_EXCHANGE")) popt.exchange = std::atoi(e);
-  // fused top tile (plan::Stage::top): 0 = off (every stage its own launch, as before round 3)
-  if (const char* e = std::getenv("CEDR_HIP_TOP")) popt.fused_top = std::atoi(e) != 0;
-  if (const char* e = std::getenv("CEDR_HIP_TOP_MAX")) popt.top_max_inputs = std::atoi(e);
+  engine::plan_options(popt);
   eng_.reset(new engine::TreeEngine(p, tree, *ns_, popt));
   m_.reset(new Impl());
 }

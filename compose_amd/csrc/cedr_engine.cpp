@@ -1,6 +1,7 @@
 #include "cedr_engine.hpp"
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 
 
@@ -11,6 +12,42 @@ namespace engine {
     const int _e_ = (call);                                             \
     cedr_throw_if(_e_ != 0, "kernel launch failed with HIP error " << _e_ << " in " #call); \
   } while (0)
+
+void plan_options (plan::Options& o) {
+  if (const char* e = std::getenv("CEDR_HIP_TILE_LEAVES")) o.max_tile_leaves = std::atoi(e);
+  if (const char* e = std::getenv("CEDR_HIP_MICRO")) {  // 0 = off, 1 = first stage only, 2 = all stages
+    o.micro = std::atoi(e) != 0;
+    o.micro_all = std::atoi(e) >= 2;
+  }
+  if (const char* e = std::getenv("CEDR_HIP_MICRO_CUT")) o.micro_cut = std::atoi(e);
+  if (const char* e = std::getenv("CEDR_HIP_MICRO_CUT2")) o.micro_cut2 = std::atoi(e);
+  // 1 = all-gather + replicated top, 2 = per-level point-to-point; default: decided from the tree
+  if (const char* e = std::getenv("CEDR_HIP_EXCHANGE")) o.exchange = std::atoi(e);
+  // fused top tile (plan::Stage::top): 0 = off (every stage its own launch, as before round 3)
+  if (const char* e = std::getenv("CEDR_HIP_TOP")) o.fused_top = std::atoi(e) != 0;
+  if (const char* e = std::getenv("CEDR_HIP_TOP_MAX")) o.top_max_inputs = std::atoi(e);
+  // The top kernels' LDS request must be grantable: (4 + kTRS = 9) doubles per internal node of the tile
+  // (inputs - 1 of them) + up to ~9 KB for the apex tile and the tables (cedr_hip_qlt_top). Every rank of a run
+  // sits on the same kind of GPU, so all ranks decide alike. Without a GPU (host-only planning) nothing is capped.
+  int dev = 0, lds = 0, optin = 0;
+  if (o.fused_top && hipGetDevice(&dev) == hipSuccess &&
+      hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) == hipSuccess && lds > 0) {
+    // (what hipFuncSetAttribute can raise a kernel's dynamic LDS to, where the runtime tells)
+    if (hipDeviceGetAttribute(&optin, hipDeviceAttributeSharedMemPerBlockOptin, dev) == hipSuccess && optin > lds)
+      lds = optin;
+    else
+      (void) hipGetLastError();
+    if (std::getenv("CEDR_HIP_PLAN_VERBOSE")) std::fprintf(stderr, "cedr: device %d grants %d B of LDS per workgroup\n", dev, lds);
+    const int64_t room = static_cast<int64_t>(lds) - 10*1024;
+    int32_t cap = 2;
+    while (cap < 2048 && 72*static_cast<int64_t>(2*cap - 1) <= room) cap *= 2;
+    if (72*static_cast<int64_t>(cap - 1) > room) o.fused_top = false;           // not even a 2-input tile
+    else if (cap < 256) o.fused_top = false;                                     // too small to replace a stage
+    else if (o.top_max_inputs > cap) o.top_max_inputs = cap;
+  } else {
+    (void) hipGetLastError();
+  }
+}
 
 void DeviceStage::upload (const plan::Stage& st) {
   static_assert(sizeof(plan::Tile) == sizeof(cedr_hip_tile), "tile layouts must agree");
@@ -92,7 +129,9 @@ TreeEngine::TreeEngine (const mpi::Parallel::Ptr& p, const tree::FlatTree& t,
                   "which needs one round of point-to-point messages per tree level, but the communicator has "
                   "no point-to-point exchange (mpi::Comm::has_exchange): pass make_parallel_callbacks its "
                   "third callback, use RCCL, or the MPI adapter");
-    popt.exchange = 1;
+    // exchange stays as the caller set it (0 = decide): plan::build takes the all-gather wherever level mode
+    // would have been chosen for size reasons (with a warning), and throws if a tree::Node::rank pin would be dropped.
+    popt.no_p2p = true;
   }
   ptm.lap("engine: leaf slots");
   plan_ = plan::build(t, me, p->size(), leaf_slot, popt);

@@ -23,6 +23,13 @@ struct DeviceStage {
   void upload(const plan::Stage& st);
 };
 
+// The planner's options as every CDR of this build sets them: the tuning / testing knobs of the environment
+// (CEDR_HIP_TILE_LEAVES, CEDR_HIP_MICRO, CEDR_HIP_MICRO_CUT, CEDR_HIP_MICRO_CUT2, CEDR_HIP_EXCHANGE, CEDR_HIP_TOP,
+// CEDR_HIP_TOP_MAX) and, when a GPU is present, the fused top tile bounded by what the device grants a workgroup in
+// LDS (the top kernels keep 72 B per internal node there + the apex: 147 KB + 9 KB for 2048 inputs, which fits
+// gfx950's 160 KB; a device with less gets a smaller top tile, one with < 24 KB none -- the per-stage launches).
+void plan_options (plan::Options& o);
+
 class TreeEngine {
 public:
   TreeEngine(const mpi::Parallel::Ptr& p, const tree::FlatTree& t, const tree::NodeSets& ns,

@@ -40,9 +40,12 @@ struct Comm {
   // the default (an error if such a plan is run).
   struct P2P { int peer; Real* buf; size_t count; int send; };
   virtual int exchange (const P2P* /*ops*/, int nops, hipStream_t /*stream*/) { return nops == 0 ? 0 : -2; }
-  // Whether exchange() is implemented. A transport without it runs every full tree through the
-  // all-gather (TreeEngine plans accordingly) and rejects partial trees when the CDR is constructed
-  // -- on every rank alike -- instead of failing inside run().
+  // Whether exchange() is implemented. REQUIRED OVERRIDE for a subclass that implements exchange(): the
+  // default (false) tells TreeEngine to plan every full tree for the all-gather (with a warning on stderr
+  // where ownership is so scattered that the planner would have preferred per-level messages) and to refuse,
+  // when the CDR is constructed and on every rank alike, what only per-level messages can do: partial
+  // trees (tree::Node::level) and nodes pinned to a rank that does not own the cells below them
+  // (tree::Node::rank) -- instead of failing inside run() or silently computing the node elsewhere.
   virtual bool has_exchange () const { return false; }
 };
 

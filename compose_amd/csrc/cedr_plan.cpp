@@ -2,6 +2,7 @@
 #include "cedr_plan.hpp"
 
 #include <algorithm>
+#include <cstdio>
 
 #include "cedr_util.hpp"
 
@@ -401,6 +402,9 @@ Plan build (const tree::FlatTree& t, int32_t my_rank, int32_t nranks,
     if (t.level[n] >= 0 || (t.nkids[n] != 2 && t.nkids[n] != 0)) partial = true;
   cedr_throw_if(partial && opt.exchange == 1,
                 "a partial tree (Node::level) cannot use the all-gather exchange");
+  cedr_throw_if(nranks > 1 && opt.no_p2p && (partial || opt.exchange == 2),
+                "a partial tree (tree::Node::level), or exchange == 2, needs one round of point-to-point messages "
+                "per tree level, which this communicator does not have (mpi::Comm::has_exchange)");
   if (nranks > 1 && (partial || opt.exchange == 2)) return build_level_mode(t, my_rank, nranks, leaf_slot, opt);
 
   // own[n]: the rank owning every leaf below n, or -1 if more than one does.
@@ -424,6 +428,10 @@ Plan build (const tree::FlatTree& t, int32_t my_rank, int32_t nranks,
   // The replicated-top design takes ownership from the leaves. A caller that pins a node inside a
   // single-rank subtree to ANOTHER rank (tree::Node::rank) wants that node computed there; level
   // mode does exactly that (every rank sees the same full tree here, so all decide alike).
+  cedr_throw_if(pinned_inside && opt.exchange == 0 && nranks > 1 && opt.no_p2p,
+                "tree::Node::rank pins a node to another rank than the one owning every cell below it; computing "
+                "it there needs point-to-point messages per tree level, which this communicator does not have "
+                "(mpi::Comm::has_exchange): override has_exchange() / exchange(), or drop the pin");
   if (pinned_inside && opt.exchange == 0 && nranks > 1) return build_level_mode(t, my_rank, nranks, leaf_slot, opt);
 
   // Boundary roots = roots of maximal single-rank subtrees, in DFS order.
@@ -447,7 +455,18 @@ Plan build (const tree::FlatTree& t, int32_t my_rank, int32_t nranks,
     std::vector<int64_t> per_rank(nranks, 0);
     for (const int32_t r : broots) ++per_rank[own[r]];
     const int64_t nb_max = *std::max_element(per_rank.begin(), per_rank.end());
-    if (nranks*nb_max > 16384 + 2*ncells/nranks) return build_level_mode(t, my_rank, nranks, leaf_slot, opt);
+    if (nranks*nb_max > 16384 + 2*ncells/nranks) {
+      if ( ! opt.no_p2p) return build_level_mode(t, my_rank, nranks, leaf_slot, opt);
+      static bool warned = false;
+      if ( ! warned && my_rank == 0) {
+        warned = true;
+        std::fprintf(stderr, "cedr (hip): ownership is scattered (%lld boundary subtrees per rank at most, %lld cells "
+                     "on %d ranks) and the communicator has no point-to-point exchange (mpi::Comm::has_exchange): "
+                     "falling back to one all-gather of %lld records; every rank then holds and sweeps about the "
+                     "whole tree.\n", static_cast<long long>(nb_max), static_cast<long long>(ncells), nranks,
+                     static_cast<long long>(nranks*nb_max));
+      }
+    }
   }
 
   Builder b(t, opt);

@@ -138,6 +138,12 @@ struct Options {
   // 2 = level mode. Every rank must use the same value; the automatic rule only looks at numbers
   // every rank computes alike.
   int32_t exchange = 0;
+  // The transport has no point-to-point messages (mpi::Comm::has_exchange() is false), so level mode
+  // cannot run: a plan that would have chosen it (exchange == 0) takes the all-gather instead where
+  // that is still correct (scattered ownership of a full tree: with a warning, once per process, since
+  // every rank then holds and sweeps about the whole tree) and throws where it is not (tree::Node::rank
+  // pins a node to another rank than the owner of everything below it; partial trees; exchange == 2).
+  bool no_p2p = false;
   // The last local stages as one fused top tile (Stage::top) once at most top_max_inputs slots
   // are left below this rank's unfinished roots; every micro stage before it is then cut
   // (micro_cut2 from the second on): the levels a cut leaves out end up in the top tile's single

@@ -118,19 +118,7 @@ void QLTHip::init (const Parallel::Ptr& p, const Int& ncells, const tree::FlatTr
   }
   gci2lci_.finish();
   plan::Options popt;
-  // Tuning / testing knobs: tile size of the non-micro stages, micro tiles on or off.
-  if (const char* e = std::getenv("CEDR_HIP_TILE_LEAVES")) popt.max_tile_leaves = std::atoi(e);
-  if (const char* e = std::getenv("CEDR_HIP_MICRO")) {  // 0 = off, 1 = first stage only, 2 = all stages
-    popt.micro = std::atoi(e) != 0;
-    popt.micro_all = std::atoi(e) >= 2;
-  }
-  if (const char* e = std::getenv("CEDR_HIP_MICRO_CUT")) popt.micro_cut = std::atoi(e);
-  if (const char* e = std::getenv("CEDR_HIP_MICRO_CUT2")) popt.micro_cut2 = std::atoi(e);
-  // 1 = all-gather + replicated top, 2 = per-level point-to-point; default: decided from the tree
-  if (const char* e = std::getenv("CEDR_HIP_EXCHANGE")) popt.exchange = std::atoi(e);
-  // fused top tile (plan::Stage::top): 0 = off (every stage its own launch, as before round 3)
-  if (const char* e = std::getenv("CEDR_HIP_TOP")) popt.fused_top = std::atoi(e) != 0;
-  if (const char* e = std::getenv("CEDR_HIP_TOP_MAX")) popt.top_max_inputs = std::atoi(e);
+  engine::plan_options(popt);  // the environment's knobs; the fused top tile bounded by the device's LDS
   eng_.reset(new engine::TreeEngine(p, tree, *ns_, popt));
   mdb_.reset(new std::vector<int>());
   d_.reset(new Impl());
@@ -294,12 +282,24 @@ void QLTHip::finish_setup () {
         const float down = eng_->time_first_stage_down(&d.lay, l2r, r2l, d.stream);
         return down > 0 ? up + down : -1;
       };
+      bool timed = false;  // a timed sweep has written into the buffers: zero them again afterwards, whatever happens
       const auto pick = [&] (dev::Buffer<Real>& own, const size_t n, const bool is_l2r) -> bool {
+        timed = true;
         float best = is_l2r ? score(own.data(), d.r2l_own.data(), true) : score(d.l2r_own.data(), own.data(), false);
         if (verbose) std::fprintf(stderr, "cedr: %s placement try 0: %.4f ms\n", is_l2r ? "l2r" : "r2l", best);
         if (best <= 0) return false;
         std::vector<std::unique_ptr<dev::Buffer<Real> > > parked;
         for (int t = 1; t < tries; ++t) {
+          // Another candidate only while the device keeps twice its size free afterwards: the tries are a transient
+          // grab of up to (tries - 1) more copies of the buffer, and a GPU shared with a host model (or its caching
+          // allocator) must not be starved by them.
+          size_t free_b = 0, total_b = 0;
+          if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void) hipGetLastError(); break; }
+          if (free_b < 3*n*sizeof(Real)) {
+            if (verbose) std::fprintf(stderr, "cedr: %s placement: %.1f GB free, no further tries\n",
+                                      is_l2r ? "l2r" : "r2l", free_b*1e-9);
+            break;
+          }
           std::unique_ptr<dev::Buffer<Real> > c(new dev::Buffer<Real>());
           try { c->alloc_zero(n); }
           catch (const std::exception&) { (void) hipGetLastError(); break; }  // out of memory: keep what we have
@@ -311,10 +311,13 @@ void QLTHip::finish_setup () {
         }
         return true;
       };
-      if (pick(d.l2r_own, nl2r, true)) {
-        pick(d.r2l_own, nr2l, false);
-        cedr_hip_check(hipMemset(d.l2r_own.data(), 0, nl2r*sizeof(Real)));  // the timed sweeps wrote into both
-        cedr_hip_check(hipMemset(d.r2l_own.data(), 0, nr2l*sizeof(Real)));
+      // (The sweeps are timed on zeros: every node problem then takes its quick exit, so the root->leaves time is
+      // its memory side alone -- which is what an allocation changes; the 0.5 % threshold only avoids swaps for nothing.)
+      if (pick(d.l2r_own, nl2r, true)) pick(d.r2l_own, nr2l, false);
+      if (timed) {
+        cedr_hip_check(hipMemsetAsync(d.l2r_own.data(), 0, nl2r*sizeof(Real), d.stream));
+        cedr_hip_check(hipMemsetAsync(d.r2l_own.data(), 0, nr2l*sizeof(Real), d.stream));
+        cedr_hip_check(hipStreamSynchronize(d.stream));
       }
     }
     d.l2r = d.l2r_own.data();

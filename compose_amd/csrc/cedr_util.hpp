@@ -42,12 +42,14 @@ class IdMap {
   std::vector<std::pair<int,int> > v_;
   std::vector<int> dense_;  // a rank's ids are usually one block with few gaps: then a direct table
   long lo_ = 0;             // ... of ids lo_ .. lo_ + dense_.size() - 1
+  size_t n_ = 0;            // entries added
   bool sorted_ = true;
 public:
   void reserve (size_t n) { v_.reserve(n); }
   void add (int id, int idx) {
     if ( ! v_.empty() && id <= v_.back().first) sorted_ = false;
     v_.emplace_back(id, idx);
+    ++n_;
   }
   void finish () {
     if (v_.empty()) return;
@@ -56,21 +58,28 @@ public:
     if (hi - lo < 4*static_cast<long>(v_.size()) + 1024) {
       lo_ = lo;
       dense_.assign(static_cast<size_t>(hi - lo) + 1, -1);
-      for (const auto& e : v_) dense_[e.first - lo] = e.second;
+      // (a duplicate id keeps its FIRST index, as the sorted form's lower_bound finds it)
+      for (const auto& e : v_) if (dense_[e.first - lo] < 0) dense_[e.first - lo] = e.second;
       std::vector<std::pair<int,int> >().swap(v_);
       sorted_ = true;
       return;
     }
-    if ( ! sorted_) { std::sort(v_.begin(), v_.end()); sorted_ = true; }
+    // (stable, by id only: among duplicates of an id the first one added stays first)
+    if ( ! sorted_) {
+      std::stable_sort(v_.begin(), v_.end(), [] (const std::pair<int,int>& a, const std::pair<int,int>& b) {
+        return a.first < b.first; });
+      sorted_ = true;
+    }
   }
-  size_t size () const { return dense_.empty() ? v_.size() : dense_.size(); }
+  size_t size () const { return n_; }  // entries added (not the span of the ids)
   // -1 if absent
   int find (int id) const {
     if ( ! dense_.empty()) {
       const long k = static_cast<long>(id) - lo_;
       return (k >= 0 && static_cast<size_t>(k) < dense_.size()) ? dense_[k] : -1;
     }
-    const auto it = std::lower_bound(v_.begin(), v_.end(), std::make_pair(id, -1));
+    const auto it = std::lower_bound(v_.begin(), v_.end(), id,
+                                     [] (const std::pair<int,int>& a, const int b) { return a.first < b; });
     return (it != v_.end() && it->first == id) ? it->second : -1;
   }
 };

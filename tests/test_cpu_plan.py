@@ -374,3 +374,30 @@ def test_plan_invariants_under_sanitizers():
     subprocess.check_call(["make", "-s", "-C", d, "plan_check_asan"])
     res = subprocess.run([os.path.join(d, "plan_check_asan")], capture_output=True, text=True, timeout=900)
     assert res.returncode == 0 and "PASS" in res.stdout, res.stdout[-2000:] + res.stderr[-3000:]
+
+
+def test_transport_without_point_to_point_refuses_what_it_would_drop(ca, capfd):
+    """mpi::Comm::has_exchange() false (two-callback transport): a tree::Node::rank pin that only level mode
+    honours is an error at construction (it used to be dropped silently); scattered ownership of a full tree
+    still plans for the all-gather, with a warning on rank 0's stderr."""
+    bad = lambda *a: 1
+    # four cells, ranks 0 0 1 1; the node over cells 0 and 1 pinned to rank 1
+    kid0 = [-1, -1, -1, -1, 0, 2, 4]
+    kid1 = [-1, -1, -1, -1, 1, 3, 5]
+    cell = [0, 1, 2, 3, -1, -1, -1]
+    for pinned in (False, True):
+        rank = [0, 0, 1, 1, 1 if pinned else -1, -1, -1]
+        tree = lambda: ca.Tree.from_arrays(6, kid0, kid1, rank, cell)
+        ca.QLT(ca.Parallel.callbacks_p2p(0, 2, bad, bad, bad), 4, tree())  # with messages: fine either way
+        if pinned:
+            with pytest.raises(ca.CedrError, match="pins a node"):
+                ca.QLT(ca.Parallel.callbacks(0, 2, bad, bad), 4, tree())
+        else:
+            ca.QLT(ca.Parallel.callbacks(0, 2, bad, bad), 4, tree())
+    nc = 40000  # pseudorandom ownership: level mode by the planner's own rule
+    capfd.readouterr()
+    q = ca.QLT(ca.Parallel.callbacks(0, 4, bad, bad), nc, ca.Tree.make_1d(nc, 4, True, False))
+    q.declare_tracer(7, 0)
+    q.end_tracer_declarations()
+    assert not q.plan()["level_mode"]
+    assert "falling back to one all-gather" in capfd.readouterr().err
