@@ -6,11 +6,14 @@
 // product and sum must round exactly as the reference's (unfused) arithmetic.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cfloat>
 #include <cstdint>
 #include <type_traits>
 #include <cstdlib>
+#include <mutex>
 #include <vector>
+#include <cstdio>
 
 #include "../../include/cedr_hip.h"
 #include "cedr_local.hpp"
@@ -68,6 +71,39 @@ __device__ __forceinline__ int xcd_tile (const int ntiles) {
 #else
   return blockIdx.x;
 #endif
+}
+// The same with the LAST tiles of every XCD's range dealt to several workgroups each. All workgroups of a first-stage
+// launch take about the same time (one tile, all chunks: ~60 us at 1.5M cells x 40 tracers) and there are 6.4 rounds of
+// them (5.3 for the leaves->root kernel), so towards the end the CUs drain one by one with nothing left to start.
+// Workgroups are dispatched in index order; when the tiles past the last FULL round (tail.nf per XCD) are split by
+// chunks over tail.k workgroups each, the launch ends with short workgroups that fill the draining CUs. Measured
+// (round 4, profiles/r04_experiments.md): root->leaves first stage -1.5 to -2 %, leaves->root -0.3 %.
+struct TailSplit { int nf, k; };
+struct WorkItem { int tix, c0, cstep; };
+__device__ __forceinline__ WorkItem work_item (const int ntiles, const TailSplit tail) {
+  WorkItem w{-1, static_cast<int>(blockIdx.y), static_cast<int>(gridDim.y)};
+#if CEDR_XCD_REMAP
+  const int per = (ntiles + 7) >> 3;
+  int t = blockIdx.x >> 3;
+  if (tail.k > 1 && t >= tail.nf) {
+    const int j = t - tail.nf;
+    t = tail.nf + j/tail.k;
+    w.c0 = j - (t - tail.nf)*tail.k;
+    w.cstep = tail.k;
+  }
+  const int g = (blockIdx.x & 7)*per + t;
+  if (t < per && g < ntiles) w.tix = g;
+#else
+  w.tix = blockIdx.x;
+#endif
+  return w;
+}
+inline unsigned xcd_grid_tail (const int ntiles, const TailSplit tail) {
+#if CEDR_XCD_REMAP
+  const int per = (ntiles + 7)/8;
+  if (tail.k > 1 && tail.nf < per) return 8u*static_cast<unsigned>(tail.nf + (per - tail.nf)*tail.k);
+#endif
+  return 8u*static_cast<unsigned>((ntiles + 7)/8);
 }
 inline unsigned xcd_grid (const int ntiles) {
 #if CEDR_XCD_REMAP
@@ -509,11 +545,12 @@ __global__ __launch_bounds__(kBlock)
 void tree_up_micro_kernel (const cedr_hip_stage st, const int nfields,
                            const uint8_t* __restrict__ op, const int64_t stride,
                            double* __restrict__ data, const double* const* __restrict__ in_rows,
-                           const int nrow, const int zero_init, const int pitch) {
+                           const int nrow, const int zero_init, const int pitch, const TailSplit tail) {
   static_assert(FT == 8*kNW || FT == 4*kNW || FT == 2*kNW,
                 "the prefetch wait macros are written for 2, 4 or 8 rows per wave");
   extern __shared__ double lds[];
-  const int tix = xcd_tile(st.ntiles);
+  const WorkItem wi = work_item(st.ntiles, tail);
+  const int tix = wi.tix;
   if (tix < 0) return;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & (kWave - 1);
   // (uniform stages: the micro-subtree descriptor does not wait for the tile descriptor)
@@ -578,7 +615,7 @@ void tree_up_micro_kernel (const cedr_hip_stage st, const int nfields,
 #endif
   d2v cab[NR], nab[NR];
   double ccc[NR], ncc[NR];
-  load(blockIdx.y, cab, ccc, false, true);  // blockIdx.y < nchunks by construction of the grid
+  load(wi.c0, cab, ccc, false, true);  // wi.c0 < nchunks by construction of the grid
   stage_tile_meta(st, tile, kidsL, lvlL);
   if constexpr (FT == 8*kNW) { CEDR_WAIT_VM0_8(cab, ccc); }
   else if constexpr (FT == 4*kNW) { CEDR_WAIT_VM0_4(cab, ccc); }
@@ -586,10 +623,10 @@ void tree_up_micro_kernel (const cedr_hip_stage st, const int nfields,
   __syncthreads();  // opL, outL and the tile metadata staged
   STAMP(0);  // setup + first chunk's loads
 
-  for (int c = blockIdx.y; c < nchunks; c += gridDim.y) {
-    const int cn = c + gridDim.y;
+  for (int c = wi.c0; c < nchunks; c += wi.cstep) {
+    const int cn = c + wi.cstep;
 #ifdef CEDR_UP_NOPREFETCH  // experiment: no chunk in flight during the combines
-    if (c != static_cast<int>(blockIdx.y)) {
+    if (c != wi.c0) {
       load(c, cab, ccc, true, true);
       if constexpr (FT == 8*kNW) { CEDR_WAIT_VM0_8(cab, ccc); }
       else if constexpr (FT == 4*kNW) { CEDR_WAIT_VM0_4(cab, ccc); }
@@ -1106,10 +1143,11 @@ __global__ __launch_bounds__(kBlock, TW == 1 ? CEDR_DOWN_SP_WAVES1 : CEDR_DOWN_S
 void qlt_down_sp_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st,
                          double* __restrict__ l2r, double* __restrict__ r2l,
                          const double* const* __restrict__ in_rows,
-                         double* const* __restrict__ out_rows, const int nrow, const int pitch) {
+                         double* const* __restrict__ out_rows, const int nrow, const int pitch, const TailSplit tail) {
   constexpr int TT = kNW*TW;
   extern __shared__ double lds[];
-  const int tix = xcd_tile(st.ntiles);
+  const WorkItem wi = work_item(st.ntiles, tail);
+  const int tix = wi.tix;
   if (tix < 0) return;
   const int MN = st.max_nodes;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & (kWave - 1);
@@ -1165,8 +1203,13 @@ void qlt_down_sp_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st,
     }
   };
 
+#ifdef CEDR_STAMPS
+  unsigned long long acc[8] = {0,0,0,0,0,0,0,0};
+  unsigned long long t_prev = __builtin_amdgcn_s_memtime();
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+#endif
   double cur[TW][3][3], Xout[TW];
-  load(blockIdx.y, cur, Xout, false);
+  load(wi.c0, cur, Xout, false);
   if (ROWS) {
     for (int i = threadIdx.x; i < L.l2rndps; i += kBlock) inL[i] = in_rows[i];
     for (int i = threadIdx.x; i < nt; i += kBlock) outL[i] = out_rows[i];
@@ -1208,16 +1251,21 @@ void qlt_down_sp_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st,
     rho3[3*i + 2] = 1.0/w;
   }
   double* const R = recs + tt*pitch;          // this thread's record row in the LDS phases
+  STAMP(0);  // setup
 
-  for (int c = blockIdx.y; c < nchunks; c += gridDim.y) {
+  for (int c = wi.c0; c < nchunks; c += wi.cstep) {
     // Wave priority by phase (s_setprio; 0.481 -> 0.459 ms, profiles/r02_down_experiments.md 1): a SIMD holds
     // five waves of five workgroups in different phases. The register phase at the end of a chunk is
     // where all four waves of a workgroup are busy and nobody waits for anybody: lowest. A chunk's
     // loads and sums lead to the first barrier: above it. The LDS levels' node problems are done by
     // one or two waves while the others of the workgroup wait at a barrier: highest.
     __builtin_amdgcn_s_setprio(kPrioLoads);
-    if (c != static_cast<int>(blockIdx.y)) load(c, cur, Xout, true);
+    if (c != wi.c0) load(c, cur, Xout, true);
 
+#ifdef CEDR_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(cur[0][0][0]), "+v"(cur[0][1][1]), "+v"(cur[0][2][2]), "+v"(Xout[0]) :: "memory");
+#endif
+    STAMP(1);  // loads arrived
     // ---- this wave's tracers: micro-subtree sums in registers, root records to LDS, the sums
     // of the LDS tree's nodes above them and the outputs' assigned masses -- all by this wave
     // alone, so no workgroup barrier separates the levels. (The previous chunk's last reads of
@@ -1256,7 +1304,9 @@ void qlt_down_sp_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st,
       const int biw = c*TT + wave + kNW*s;
       if (biw < nt && lane < tile.nout) recs[(wave + kNW*s)*pitch + kRS*onodeL[lane] + 3] = Xout[s];
     }
+    STAMP(2);  // sums + level sums
     __syncthreads();
+    STAMP(3);  // first barrier
     // ---- node problems of the LDS levels, from the tile's outputs down, (node, tracer) items
     // spread over all threads
     __builtin_amdgcn_s_setprio(kPrioLdsLevels);
@@ -1280,16 +1330,17 @@ void qlt_down_sp_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st,
       __syncthreads();
     }
     __builtin_amdgcn_s_setprio(0);
+    STAMP(4);  // LDS levels' node problems + their barriers
 
     // ---- this wave's tracers again: the micro-subtree's node problems in registers
 #pragma unroll
     for (int s = 0; s < TW; ++s) {
       const int biw = c*TT + wave + kNW*s;
       if (biw >= nt || lane >= nleaf) continue;
+      const double Xr = recs[(wave + kNW*s)*pitch + kRS*lane + 3];
       double T[3];  // inner pair t: {lo, orig, hi} sums, re-formed
 #pragma unroll
       for (int f = 0; f < 3; ++f) T[f] = cur[s][0][f] + cur[s][1][f];
-      const double Xr = recs[(wave + kNW*s)*pitch + kRS*lane + 3];
       double Xt = Xr, Xu = Xr, Xv = 0, Xp = 0;
       const KidRho kt{cellrho[9*kWave + lane], cellrho[10*kWave + lane], cellrho[11*kWave + lane]};
       if ((any2 && m.shape == 2) || (any3 && m.shape == 3)) {
@@ -1312,7 +1363,12 @@ void qlt_down_sp_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st,
       double* __restrict__ const orow = (ROWS ? outL[biw] : r2l + static_cast<size_t>(r2lL[biw])*S) + tile.in0;
       store_roles(orow, ro, Xu, Xv, Xp);
     }
+    STAMP(5);  // register node problems + stores issued
   }
+#ifdef CEDR_STAMPS
+  if (lane == 0)
+    for (int i = 0; i < 6; ++i) atomicAdd(&g_stamps[wave*8 + i], acc[i]);
+#endif
 }
 
 // reference cedr_qlt.cpp:453-473 (root_compute), one thread per bulk index.
@@ -2639,6 +2695,10 @@ inline int pitch_for (int n) { return (n + 30)/32*32 + 1; }
 // 5 chunks per tile instead of 4 + 4 + 2: 0.0549 -> 0.0534 ms at 1.5M cells' second stage, 0.0706 -> 0.0695 ms at the
 // shard's first; 5120 and 10240 are slower.)
 constexpr int kSplitUp = 1024, kSplitDown = 2048;  // kSplitDown: micro tiles only
+#ifndef CEDR_TAIL_K
+# define CEDR_TAIL_K 5
+#endif
+constexpr int kTailK = CEDR_TAIL_K;
 // (Round 2: splitting the first stage's tiles too -- 9000 or 17000 workgroups wanted -- does not shorten
 // the last, partly idle round: 0.488 -> 0.492 / 0.514 ms.)
 inline int chunk_split (int ntiles, int nchunks, int target) {
@@ -2647,6 +2707,51 @@ inline int chunk_split (int ntiles, int nchunks, int target) {
   if (y < 1) y = 1;
   const int per = (nchunks + y - 1)/y;  // chunks per workgroup
   return (nchunks + per - 1)/per;
+}
+
+// The tail split of a first-stage launch (work_item): with 'wgs' resident workgroups per XCD (occupancy x 32 CUs), the
+// tiles of an XCD's range that lie past its last full round go to k workgroups each. Only for stages of at least two
+// full rounds whose chunks are not split already; CEDR_HIP_TAIL = k (default 5; 0 or 1 = off), CEDR_HIP_TAIL_ROUNDS = r
+// (default 0): r more full rounds are split as well.
+template <typename K>
+TailSplit tail_split (K kernel, const size_t lds, const int ntiles, const int nchunks, const int ysplit) {
+  static const int k_env = [] { const char* v = std::getenv("CEDR_HIP_TAIL"); return v ? std::atoi(v) : kTailK; }();
+  static const int r_env = [] { const char* v = std::getenv("CEDR_HIP_TAIL_ROUNDS"); return v ? std::atoi(v) : 0; }();
+  TailSplit t{0, 1};
+  if (k_env < 2 || ysplit != 1 || nchunks < 2) return t;
+  // (resident workgroups per XCD for this kernel and LDS size: asked once, the answer is kept -- the query is not
+  // free and run() launches this on every step; a handful of (kernel, lds) pairs per process)
+  struct Known { const void* k; size_t lds; int dev, wgs; };
+  static std::vector<Known> known;
+  static std::mutex mtx;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { (void) hipGetLastError(); return t; }
+  int wgs = -1;
+  {
+    std::lock_guard<std::mutex> lock(mtx);
+    for (const Known& kn : known)
+      if (kn.k == reinterpret_cast<const void*>(kernel) && kn.lds == lds && kn.dev == dev) wgs = kn.wgs;
+    if (wgs < 0) {
+      int occ = 0, ncu = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, kBlock, lds) != hipSuccess || occ < 1 ||
+          hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu < 8) {
+        (void) hipGetLastError();
+        wgs = 0;
+      } else {
+        wgs = occ*(ncu/8);
+      }
+      if (std::getenv("CEDR_HIP_TAIL_VERBOSE"))
+        std::fprintf(stderr, "cedr: tail split: %d workgroups per CU, %d CUs, lds %zu\n", occ, ncu, lds);
+      known.push_back(Known{reinterpret_cast<const void*>(kernel), lds, dev, wgs});
+    }
+  }
+  if (wgs < 1) return t;
+  const int per = (ntiles + 7)/8;
+  const int rounds = per/wgs - r_env;
+  if (rounds < 2 || per % wgs == 0) return t;
+  t.nf = rounds*wgs;
+  t.k = std::min(k_env, nchunks);
+  return t;
 }
 
 }  // namespace
@@ -2704,8 +2809,9 @@ int cedr_hip_tree_up_rows_sums (const cedr_hip_stage* st, int32_t nfields, const
     auto go = [&] (auto kernel) -> int {
       int e = set_lds_limit(kernel, lds);
       if (e) return e;
-      hipLaunchKernelGGL(kernel, gridx, dim3(kBlock), lds, stream,
-                         *st, nfields, op, stride, data, in_rows, nrow, zero_init, pitch);
+      const TailSplit tail = tail_split(kernel, lds, st->ntiles, (nfields + FTr - 1)/FTr, gridx.y);
+      hipLaunchKernelGGL(kernel, dim3(xcd_grid_tail(st->ntiles, tail), gridx.y), dim3(kBlock), lds, stream,
+                         *st, nfields, op, stride, data, in_rows, nrow, zero_init, pitch, tail);
       return 0;
     };
     const bool sums = all_sums && ! zero_init;
@@ -2781,8 +2887,9 @@ int cedr_hip_qlt_down_rows (const cedr_hip_qlt_layout* lay, const cedr_hip_stage
       auto gosp = [&] (auto kernel) -> int {
         int e2 = set_lds_limit(kernel, ldss);
         if (e2) return e2;
-        hipLaunchKernelGGL(kernel, gridm, dim3(kBlock), ldss, stream,
-                           *lay, *st, l2r, r2l, in_rows, out_rows, nrow, pitchs);
+        const TailSplit tail = tail_split(kernel, ldss, st->ntiles, (nt + TTm - 1)/TTm, gridm.y);
+        hipLaunchKernelGGL(kernel, dim3(xcd_grid_tail(st->ntiles, tail), gridm.y), dim3(kBlock), ldss, stream,
+                           *lay, *st, l2r, r2l, in_rows, out_rows, nrow, pitchs, tail);
         return 0;
       };
       if (tw == 1) e = in_rows ? gosp(qlt_down_sp_kernel<1, true>) : gosp(qlt_down_sp_kernel<1, false>);

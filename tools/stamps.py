@@ -1,6 +1,6 @@
 """Diagnostic: phase shares of the micro down kernel from a -DCEDR_STAMPS build."""
 import ctypes as C, os, sys
-os.environ["CEDR_HIP_LIB"] = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "compose_amd", "variants", "stamps.so")
+os.environ["CEDR_HIP_LIB"] = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "compose_amd", "variants", os.environ.get("CEDR_STAMPS_LIB", "stamps.so"))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torch, compose_amd as ca
 sys.argv = ["bench"]
@@ -19,7 +19,7 @@ buf = (C.c_ulonglong * 64)()
 q.run(); torch.cuda.synchronize(); L.cedr_hip_debug_stamps(buf, 1)
 for _ in range(3): q.run()
 torch.cuda.synchronize(); L.cedr_hip_debug_stamps(buf, 1)
-names = ["setup", "load+micro sums", "barrier1", "phase A", "phase B", "register solves"]
+names = ["setup", "loads arrive", "sums", "barrier1", "LDS NPs", "register NPs+stores"]
 unames = ["setup+first loads", "issue prefetch+micro combines", "barrier", "LDS levels", "outputs+barrier", "wait prefetch"]
 for w in range(4):
     tot = sum(buf[w*8+i] for i in range(6))
