@@ -695,6 +695,14 @@ void tree_up_micro_kernel (const cedr_hip_stage st, const int nfields,
     if (fl < nfields)
       for (int k = lane >> LR; k < tile.nout; k += kWave/NR)
         data[static_cast<size_t>(160)*stride + static_cast<size_t>(tix)*nfields*16 % (stride - 4096) + fl*16 + k] = vr[outL[k]];
+#elif defined(CEDR_DIAG_UP_ONELINE)  // (diagnostic builds, wrong results: every tile writes the SAME 161 lines: the stores without their memory traffic)
+    if (fl < nfields)
+      for (int k = lane >> LR; k < tile.nout; k += kWave/NR)
+        data[static_cast<size_t>(fl)*stride + st.tiles[0].out + 16*(blockIdx.x & 7) + k] = vr[outL[k]];
+#elif defined(CEDR_DIAG_UP_EIGHTH)  // (diagnostic builds, wrong results: one tile in eight writes its outputs)
+    if (fl < nfields && (tix & 7) == 0)
+      for (int k = lane >> LR; k < tile.nout; k += kWave/NR)
+        data[static_cast<size_t>(fl)*stride + tile.out + k] = vr[outL[k]];
 #elif ! defined(CEDR_DIAG_UP_NOSTORE)  // (diagnostic builds: the sweep without its output stores)
     if (fl < nfields)
       for (int k = lane >> LR; k < tile.nout; k += kWave/NR)
