@@ -1225,6 +1225,12 @@ void qlt_down_sp_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st,
   for (int i = threadIdx.x; i < nt; i += kBlock) { fldL[i] = L.bidx_l2r[i]; r2lL[i] = L.bidx_r2l[i]; }
   for (int i = threadIdx.x; i < tile.nout; i += kBlock) onodeL[i] = st.outs[tile.outs_off + i];
 
+#ifdef CEDR_DIAG_NOSETUP  // (diagnostic builds, wrong results: the tile's densities are constants -- no loads, divisions or level sums)
+  for (int i = threadIdx.x; i < 3*MN; i += kBlock) rho3[i] = 1.0;
+  for (int i = threadIdx.x; i < kCellRho*kWave; i += kBlock) cellrho[i] = 1.0;
+  stage_tile_meta(st, tile, kidsL, lvlL);
+  __syncthreads();
+#else
   // Densities: wave r derives role r of every micro-subtree (u, v, p, inner pair t):
   // two divisions per thread. Wave 3 also has the micro-subtree's root density.
   {
@@ -1258,6 +1264,7 @@ void qlt_down_sp_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st,
     rho3[3*i + 1] = w;
     rho3[3*i + 2] = 1.0/w;
   }
+#endif
   double* const R = recs + tt*pitch;          // this thread's record row in the LDS phases
   STAMP(0);  // setup
 

@@ -5,7 +5,7 @@ one GPU and at the 187.5k-cell shard (rank 0 of 8, stub transport). Times CAAS::
     reduce (clip + group sums): 40 B per cell-tracer + 32/accum B (the 4 partial sums per group it writes)
     the reducer's leaves->root sweep: reads those partials once: 32/accum B per cell-tracer
     finish: 24 B per cell-tracer
-Writes gpurun_out/r03_caas_bfb.json and .csv (copy to profiles/)."""
+Writes gpurun_out/<RN>_caas_bfb.json and .csv (RN from the environment, default r04; copy to profiles/)."""
 import json, os, subprocess, sys, time
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, ROOT); sys.argv = ["x"]
@@ -81,8 +81,8 @@ try:
 except OSError:
     head = "unknown"
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-json.dump(dict(head=head, peak_GBs=PEAK, runs=res), open(os.path.join(ROOT, "gpurun_out", "r03_caas_bfb.json"), "w"), indent=1)
-with open(os.path.join(ROOT, "gpurun_out", "r03_caas_bfb.csv"), "w") as f:
+json.dump(dict(head=head, peak_GBs=PEAK, runs=res), open(os.path.join(ROOT, "gpurun_out", os.environ.get("RN", "r04") + "_caas_bfb.json"), "w"), indent=1)
+with open(os.path.join(ROOT, "gpurun_out", os.environ.get("RN", "r04") + "_caas_bfb.csv"), "w") as f:
     f.write("config,kernel,launch,launches_per_run,avg_ms\n")
     for r in res:
         for k in r.get("launches", []):
