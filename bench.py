@@ -476,6 +476,8 @@ def main():
             break
         except (OSError, ValueError, KeyError):
             continue
+    grids = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_kernel_stats_by_grid.csv"))
+    by_grid = "profiles/" + grids[-1] if grids else "a by-grid split of the kernel trace"
     dom = next((k for k in kernels if "achieved_GBs" in k), None)
     roofline = None
     if dom:
@@ -486,20 +488,22 @@ def main():
                         launch="first stage: %d workgroups (tiles)" % dom["launch"],
                         rocprof="every stage runs the same sweep kernels (qlt_down_sp_kernel / tree_up_micro_kernel),"
                                 " so rocprofv3 --stats averages all stages under one name; "
-                                "profiles/r03_kernel_stats_by_grid.csv splits the same trace by kernel instantiation "
-                                "and launch grid (tools/kernel_stats_by_grid.py)")
+                                "%s splits the same trace by kernel instantiation "
+                                "and launch grid (tools/kernel_stats_by_grid.py)" % by_grid)
         if dom["kernel"] == "qlt_down_kernel":
-            roofline["bound_note"] = ("reported against the HBM roofline, the metric's roofline. Round 3 took a third of "
-                                      "the node problems' vector instructions out (predicates kept as scalar lane masks: "
-                                      "0.445 -> 0.405 ms); further cuts buy nothing, a sixth wave per SIMD needs 80 VGPRs "
-                                      "(spills: +20 %): the kernel sits on its streaming skeleton at five waves per SIMD "
-                                      "(profiles/r03_experiments.md 11)")
+            roofline["bound_note"] = ("reported against the HBM roofline, the metric's roofline. Without any node problem the "
+                                      "kernel takes 0.36 ms: what the memory system delivers to its access pattern (three read "
+                                      "rows and one written row per tracer in 1.4 KB pieces 12 MB apart) at five workgroups per "
+                                      "CU; neither a prefetch of the next chunk by LDS-DMA nor a cheaper per-tile setup moves "
+                                      "that, one wave per SIMD less costs 10 %, and the node problems add 0.03-0.04 ms "
+                                      "(profiles/r04_experiments.md 1, 5)")
         elif dom["kernel"] == "tree_up_kernel":
-            roofline["bound_note"] = ("the reads stream at the copy rate (0.31 ms); the gap is the 1.3 M isolated 128-byte "
-                                      "output lines written between them (profiles/r02_down_experiments.md 2). This kernel "
-                                      "takes 0.383-0.387 ms in some processes and 0.40-0.43 ms in others on the same box "
-                                      "with the same binary (decided at process start, profiles/r03_experiments.md 11); "
-                                      "whichever of the two first-stage sweeps is slower in this process is reported here")
+            roofline["bound_note"] = ("the reads stream at the copy rate (0.317 ms without the output stores); the gap is the 1.3 M "
+                                      "isolated 128-byte output lines written between them: free to issue (a build that writes "
+                                      "them all to the same lines runs at the no-store speed), 0.07-0.11 ms on the memory side "
+                                      "depending on which device memory the allocation got, and an eighth of them already "
+                                      "costs half of that (profiles/r04_experiments.md 3; r03_experiments.md 12). Whichever of the "
+                                      "two first-stage sweeps is slower in this process is reported here")
 
     # Pack / unpack either side of run() (reported apart from `value`).
     def timed_sync(fn, reps=5):

@@ -2730,8 +2730,10 @@ inline int chunk_split (int ntiles, int nchunks, int target) {
 // (default 0): r more full rounds are split as well.
 template <typename K>
 TailSplit tail_split (K kernel, const size_t lds, const int ntiles, const int nchunks, const int ysplit) {
-  static const int k_env = [] { const char* v = std::getenv("CEDR_HIP_TAIL"); return v ? std::atoi(v) : kTailK; }();
-  static const int r_env = [] { const char* v = std::getenv("CEDR_HIP_TAIL_ROUNDS"); return v ? std::atoi(v) : 0; }();
+  // (read at every launch, not once: the parity test switches them inside one process)
+  const char* const kv = std::getenv("CEDR_HIP_TAIL");
+  const char* const rv = std::getenv("CEDR_HIP_TAIL_ROUNDS");
+  const int k_env = kv ? std::atoi(kv) : kTailK, r_env = rv ? std::atoi(rv) : 0;
   TailSplit t{0, 1};
   if (k_env < 2 || ysplit != 1 || nchunks < 2) return t;
   // (resident workgroups per XCD for this kernel and LDS size: asked once, the answer is kept -- the query is not

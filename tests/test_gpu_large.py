@@ -281,3 +281,25 @@ def test_qlt_placement_tries_do_not_change_results(gpu, monkeypatch):
         outs.append(common.run_hip_qlt(ca, q, v))
     assert np.array_equal(outs[0], outs[1])
     assert R.check(trs, v, outs[1], False, verbose=False)[0] == 0
+
+
+def test_tail_split_does_not_change_results(gpu, oracle, monkeypatch):
+    """The first-stage launches end with short workgroups: the tiles past an XCD's last full round of workgroups are
+    dealt to several workgroups by chunks (CEDR_HIP_TAIL, CEDR_HIP_TAIL_ROUNDS). Same chunks, other workgroups: the
+    results are the oracle's bits whatever the split, for shape-preserving tracers (the specialised root->leaves
+    kernel) and for the harness's mixed types (the general one, which is launched unsplit)."""
+    ca = gpu
+    ncells = 600000  # 4096 first-stage tiles: three full rounds per XCD and a tail
+    cst = [R.Tracer(i, CST, 1 + i % 3) for i in range(12)]  # three chunks of four; perturbations that redistribute
+    for trs in (cst, R.tracers_vector()[:9]):
+        types = [t.problem_type for t in trs]
+        v = R.make_values(trs, ncells, seed=len(trs))
+        want = common.run_oracle_qlt(oracle, (False, False), ncells, 1, types, v)
+        for tail, rounds in (("0", "0"), ("2", "0"), ("5", "0"), ("3", "1"), ("64", "2")):
+            monkeypatch.setenv("CEDR_HIP_TAIL", tail)
+            monkeypatch.setenv("CEDR_HIP_TAIL_ROUNDS", rounds)
+            q = common.make_hip_qlt(ca, ca.Tree.make_1d(ncells), ncells, types)
+            assert len(q.plan()["local"][0]["tiles"]) >= 4096
+            got = common.run_hip_qlt(ca, q, v)
+            assert np.array_equal(got, want), (len(trs), tail, rounds)
+            del q
