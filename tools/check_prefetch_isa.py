@@ -46,46 +46,117 @@ def listing(extra_flags=()):
         return open(out).read()
 
 
+BRANCH = re.compile(r"^(s_cbranch_\w+|s_branch)\s+(\.L\w+)")
+
+
 def check(text):
-    """Returns (violations, stats): stats[function] = (asm loads, asm waits)."""
+    """Returns (violations, stats): stats[function] = (asm loads, asm waits).
+
+    A forward dataflow over each function's control-flow graph (basic blocks from the listing's labels and
+    s_branch / s_cbranch_* instructions): the set of VGPRs some inline-asm load may still be filling at a point is the
+    union over all paths reaching it; an inline-asm `s_waitcnt vmcnt(0)` empties it. (Until round 4 this walked the
+    listing in layout order, which missed a real hazard: a wait on a side path that happens to be laid out first
+    made the main path's copies of in-flight registers look safe.)"""
     violations, stats = [], {}
-    fn, in_asm, inflight, nload, nwait = None, False, set(), 0, 0
+    # ---- split into functions
+    funcs, fn, body = [], None, []
     for ln, line in enumerate(text.splitlines(), 1):
-        s = line.strip()
         m = re.match(r"^(_Z\w+):", line)
         if m:
-            fn, in_asm, inflight, nload, nwait = m.group(1), False, set(), 0, 0
+            fn, body = m.group(1), []
             continue
         if fn is None:
             continue
-        if s.startswith(".Lfunc_end") or s.startswith("s_endpgm"):
-            if nload or nwait:
-                stats[fn] = (nload, nwait)
-            if s.startswith(".Lfunc_end"):
-                fn = None
+        if line.strip().startswith(".Lfunc_end"):
+            funcs.append((fn, body))
+            fn = None
             continue
-        if s.startswith(";;#ASMSTART"):
-            in_asm = True
+        body.append((ln, line))
+    for fn, body in funcs:
+        # ---- basic blocks: list of (kind, ln, text, regs) items; kind in {"load", "wait", "code"}
+        blocks, labels, cur = [], {}, {"items": [], "succ": [], "fall": True}
+        blocks.append(cur)
+        in_asm, nload, nwait = False, 0, 0
+
+        def new_block():
+            nonlocal cur
+            cur = {"items": [], "succ": [], "fall": True}
+            blocks.append(cur)
+        for ln, line in body:
+            s = line.strip()
+            m = re.match(r"^(\.L\w+):", s)
+            if m and not in_asm:
+                if cur["items"] or cur["succ"]:
+                    new_block()
+                labels[m.group(1)] = len(blocks) - 1
+                continue
+            if s.startswith(";;#ASMSTART"):
+                in_asm = True
+                continue
+            if s.startswith(";;#ASMEND"):
+                in_asm = False
+                continue
+            if not s or s.startswith(";") or s.startswith(".") or s.endswith(":"):
+                continue
+            code = s.split(";")[0].strip()
+            if in_asm:
+                if re.match(r"(global|buffer|flat)_load", code) and " lds" not in code and "_lds_" not in code:
+                    dest = code.split(None, 1)[1].split(",")[0]
+                    cur["items"].append(("load", ln, s, vregs(dest)))
+                    nload += 1
+                elif code.startswith("s_waitcnt") and "vmcnt(0)" in code:
+                    cur["items"].append(("wait", ln, s, set()))
+                    nwait += 1
+                continue
+            cur["items"].append(("code", ln, s, vregs(code)))
+            mb = BRANCH.match(code)
+            if mb:
+                cur["succ"].append(mb.group(2))
+                if mb.group(1) == "s_branch":
+                    cur["fall"] = False
+                new_block()
+            elif code.startswith("s_endpgm") or code.startswith("s_setpc") or code.startswith("s_trap"):
+                cur["fall"] = False
+                new_block()
+        if not (nload or nwait):
             continue
-        if s.startswith(";;#ASMEND"):
-            in_asm = False
-            continue
-        if not s or s.startswith(";") or s.startswith(".") or s.endswith(":"):
-            continue
-        code = s.split(";")[0]
-        if in_asm:
-            if re.match(r"(global|buffer|flat)_load", code):
-                dest = code.split(None, 1)[1].split(",")[0]
-                inflight |= vregs(dest)
-                nload += 1
-            elif code.startswith("s_waitcnt") and "vmcnt(0)" in code:
-                inflight = set()
-                nwait += 1
-            continue
-        if inflight:
-            hit = vregs(code) & inflight
-            if hit:
-                violations.append((fn, ln, s, sorted(hit)))
+        stats[fn] = (nload, nwait)
+        succ = []
+        for i, b in enumerate(blocks):
+            out = [labels[t] for t in b["succ"] if t in labels]
+            if b["fall"] and i + 1 < len(blocks):
+                out.append(i + 1)
+            succ.append(out)
+        # ---- fixed point of IN sets
+        IN = [set() for _ in blocks]
+        work = list(range(len(blocks)))
+        while work:
+            i = work.pop()
+            st = set(IN[i])
+            for kind, ln, s, regs in blocks[i]["items"]:
+                if kind == "load":
+                    st |= regs
+                elif kind == "wait":
+                    st = set()
+            for j in succ[i]:
+                if not st <= IN[j]:
+                    IN[j] |= st
+                    work.append(j)
+        # ---- report
+        seen = set()
+        for i, b in enumerate(blocks):
+            st = set(IN[i])
+            for kind, ln, s, regs in b["items"]:
+                if kind == "load":
+                    st |= regs
+                elif kind == "wait":
+                    st = set()
+                elif st:
+                    hit = regs & st
+                    if hit and ln not in seen:
+                        seen.add(ln)
+                        violations.append((fn, ln, s, sorted(hit)))
+    violations.sort(key=lambda v: v[1])
     return violations, stats
 
 
