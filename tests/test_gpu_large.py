@@ -4,6 +4,7 @@ cedr_test_randomized.cpp:293-418 (bounds, mass conservation) plus a checksum com
 with the oracle on a strided sample of tracers; a 1M-cell x 600-tracer problem puts field
 offsets beyond 2^31 elements (the reference's Int indexing overflows there)."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -213,7 +214,8 @@ def test_config_C_sharded_8_ways(gpu, oracle):
                 tree = tree.prune(rank)
                 assert tree.nnodes() < 2 * (n // nranks) + 64
             q = declare(ca.QLT(par, n, tree))
-            assert q.plan()["level_mode"] == partial
+            # (CEDR_HIP_EXCHANGE=2, one of the env-matrix settings, forces level mode for full trees too)
+            assert q.plan()["level_mode"] == (partial or (nranks > 1 and os.environ.get("CEDR_HIP_EXCHANGE") == "2"))
             g = torch.from_numpy(q.get_owned_glblcells().astype(np.int64)).to(dev)
             assert int(g[0]) == rank * (n // nranks) and bool((g[1:] - g[:-1] == 1).all())  # contiguous shard
             loc = [x.index_select(x.dim() - 1, g).contiguous() for x in glob]

@@ -89,13 +89,14 @@ __global__ __launch_bounds__(256) void k_chunks (const double* __restrict__ p, i
 // WRITE 0: no result stores.
 template <int WRITE>
 __global__ __launch_bounds__(256, 5) void k_down (const double* __restrict__ l2r, double* __restrict__ r2l, int64_t stride,
-                                                   int nt, int ncell, int ntiles, int64_t out0, double* out) {
+                                                   int nt, int ncell, int ntiles, int64_t out0, double* out, int pitch = 0) {
   extern __shared__ double lds[];
   const int per = gridDim.x >> 3;
   const int t = (blockIdx.x & 7)*per + (blockIdx.x >> 3);
   if (t >= ntiles) return;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const size_t cell0 = static_cast<size_t>(t)*ncell + 3*lane;
+  if (pitch == 0) pitch = ncell;
+  const size_t cell0 = static_cast<size_t>(t)*pitch + 3*lane;
   double s = 0;
   for (int ch = 0; ch < (nt + 3)/4; ++ch) {
     int tr = 4*ch + wave; if (tr > nt - 1) tr = nt - 1;
@@ -137,7 +138,7 @@ __global__ __launch_bounds__(256, 5) void k_down (const double* __restrict__ l2r
       double* stg = lds + 256 + wave*200;
       stg[3*lane] = r0; stg[3*lane + 1] = r1; stg[3*lane + 2] = r2;
       __builtin_amdgcn_wave_barrier();
-      double* row = r2l + static_cast<size_t>(tr)*stride + static_cast<size_t>(t)*ncell;
+      double* row = r2l + static_cast<size_t>(tr)*stride + static_cast<size_t>(t)*pitch;
       for (int i = lane; 2*i < ncell; i += 64) {
         Pair ab; ab.x = stg[2*i]; ab.y = stg[2*i + 1];
         if (2*i + 1 < ncell) *reinterpret_cast<Pair*>(row + 2*i) = ab;
@@ -218,6 +219,22 @@ __global__ __launch_bounds__(256, 5) void k_wronly (double* __restrict__ r2l, in
   }
 }
 
+// (g) the same bytes in CAAS's geometry: a workgroup takes 512 contiguous cells of ONE tracer, reads its rows lo / orig / hi
+// (one 16-byte load per row and thread) and writes a result row: out of place (r2l) or in place over 'orig'.
+template <int INPLACE>
+__global__ __launch_bounds__(256) void k_caaslike (double* __restrict__ l2r, double* __restrict__ r2l, int64_t stride, int n) {
+  const int tr = blockIdx.y;
+  const size_t i = (static_cast<size_t>(blockIdx.x)*256 + threadIdx.x)*2;
+  if (i + 1 >= static_cast<size_t>(n)) return;
+  const d2* lo = reinterpret_cast<const d2*>(l2r + static_cast<size_t>(1 + 4*tr)*stride + i);
+  const d2* og = reinterpret_cast<const d2*>(l2r + static_cast<size_t>(2 + 4*tr)*stride + i);
+  const d2* hi = reinterpret_cast<const d2*>(l2r + static_cast<size_t>(3 + 4*tr)*stride + i);
+  const d2 a = __builtin_nontemporal_load(lo), b = __builtin_nontemporal_load(og), c = __builtin_nontemporal_load(hi);
+  d2 r; r.x = a.x + b.x + c.x; r.y = a.y + b.y + c.y;
+  d2* dst = reinterpret_cast<d2*>((INPLACE ? l2r + static_cast<size_t>(2 + 4*tr)*stride : r2l + static_cast<size_t>(tr)*stride) + i);
+  *dst = r;
+}
+
 int main () {
   const int ncells = 1500000, nfields = 161, ncell = 183, ntiles = 8192;
   const int64_t stride = (ncells + 8192*16 + 2 + 15)/16*16;  // field-major rows, as the QLT buffer: the cells, then 16 output slots per tile
@@ -263,6 +280,10 @@ int main () {
     timeit("root->leaves traffic, results as contiguous 16-B pieces via LDS", db, [&] { hipLaunchKernelGGL(k_down<2>, dim3(8192), dim3(256), 28*1024, 0, d, r2l, stride, nt, ncell, ntiles, static_cast<int64_t>(ncells), out); });
     timeit("root->leaves traffic, results IN PLACE over the 'orig' row just read", db, [&] { hipLaunchKernelGGL(k_down<3>, dim3(8192), dim3(256), 28*1024, 0, d, r2l, stride, nt, ncell, ntiles, static_cast<int64_t>(ncells), out); });
     timeit("root->leaves traffic, results into the tracer's 4th row of l2r", db, [&] { hipLaunchKernelGGL(k_down<4>, dim3(8192), dim3(256), 28*1024, 0, d, r2l, stride, nt, ncell, ntiles, static_cast<int64_t>(ncells), out); });
+    timeit("root->leaves traffic, 192-cell line-aligned tiles (7812), lane = 3 cells", static_cast<double>(7812)*192*(32.0*nt + 8), [&] { hipLaunchKernelGGL(k_down<1>, dim3(7816), dim3(256), 28*1024, 0, d, r2l, stride, nt, 192, 7812, static_cast<int64_t>(ncells), out, 192); });
+    timeit("root->leaves traffic, 192-cell line-aligned tiles, results as contiguous pieces", static_cast<double>(7812)*192*(32.0*nt + 8), [&] { hipLaunchKernelGGL(k_down<2>, dim3(7816), dim3(256), 28*1024, 0, d, r2l, stride, nt, 192, 7812, static_cast<int64_t>(ncells), out, 192); });
+    timeit("the same bytes in CAAS's geometry (512 cells of one tracer per WG), out of place", static_cast<double>(ncells)*32.0*nt, [&] { hipLaunchKernelGGL(k_caaslike<0>, dim3((ncells/2 + 255)/256, nt), dim3(256), 0, 0, d, r2l, stride, ncells); });
+    timeit("the same bytes in CAAS's geometry, in place over 'orig'", static_cast<double>(ncells)*32.0*nt, [&] { hipLaunchKernelGGL(k_caaslike<1>, dim3((ncells/2 + 255)/256, nt), dim3(256), 0, 0, d, r2l, stride, ncells); });
     const double wb = static_cast<double>(ntiles)*ncell*8.0*nt;
     timeit("result stores alone: lane = 3 cells, 183-cell segments", wb, [&] { hipLaunchKernelGGL(k_wronly<0>, dim3(8192), dim3(256), 28*1024, 0, r2l, stride, nt, ncell, ncell, ntiles); });
     timeit("result stores alone: contiguous 16-B pieces, 183-cell segments", wb, [&] { hipLaunchKernelGGL(k_wronly<1>, dim3(8192), dim3(256), 28*1024, 0, r2l, stride, nt, ncell, ncell, ntiles); });
