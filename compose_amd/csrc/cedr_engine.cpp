@@ -37,6 +37,9 @@ void plan_options (plan::Options& o) {
       lds = optin;
     else
       (void) hipGetLastError();
+    // (CEDR_HIP_LDS_LIMIT: plan as for a device that grants this many bytes -- how tests/test_gpu_qlt.py reaches the branches
+    // below on a GPU that has 160 KB; it can only lower the figure)
+    if (const char* e = std::getenv("CEDR_HIP_LDS_LIMIT")) { const int v = std::atoi(e); if (v > 0 && v < lds) lds = v; }
     if (std::getenv("CEDR_HIP_PLAN_VERBOSE")) std::fprintf(stderr, "cedr: device %d grants %d B of LDS per workgroup\n", dev, lds);
     const int64_t room = static_cast<int64_t>(lds) - 10*1024;
     int32_t cap = 2;

@@ -276,3 +276,29 @@ def test_qlt_on_a_cu_masked_stream(gpu, oracle):
     ms.close()
     with pytest.raises(ca.CedrError):
         ca.MaskedStream([])
+
+
+@pytest.mark.parametrize("limit,max_top_inputs", [(None, 2048), ("65536", 512), ("40000", 256), ("20000", 0)])
+def test_top_tile_follows_the_lds_the_device_grants(gpu, oracle, limit, max_top_inputs, monkeypatch):
+    """The fused top tile keeps 72 B of LDS per internal node (+ ~10 KB for the apex and tables): 2048 inputs need
+    gfx950's 160 KB. The planner sizes it from what the device grants a workgroup (CEDR_HIP_LDS_LIMIT plans as for a
+    smaller device): a smaller top tile, or none below 24 KB (one launch per stage) -- never a launch that asks for
+    more LDS than there is. Same bits either way."""
+    ca = gpu
+    if limit:
+        monkeypatch.setenv("CEDR_HIP_LDS_LIMIT", limit)
+    ncells = 40000  # 219 first-stage tiles -> 3504 outputs: more than any top tile takes, so a second stage exists
+    trs = R.tracers_vector()[:12]
+    v = R.make_values(trs, ncells, seed=3)
+    want = common.run_oracle_qlt(oracle, (False, False), ncells, 1, _types(trs), v)
+    q = common.make_hip_qlt(ca, ca.Tree.make_1d(ncells), ncells, _types(trs))
+    tops = [st for st in q.plan()["local"] if st["top"]]
+    if max_top_inputs == 0:
+        assert not tops
+    else:
+        assert len(tops) == 1
+        nin = int(tops[0]["tiles"][0][1])  # the tile's input count
+        assert 2 <= nin <= max_top_inputs, nin
+        if limit:
+            assert 72 * (nin - 1) + 10 * 1024 <= int(limit)
+    assert np.array_equal(common.run_hip_qlt(ca, q, v), want)
