@@ -129,7 +129,9 @@ struct Options {
   bool micro = true;              // first local stage uses micro tiles (64 x <= 3 leaves)
   bool micro_all = true;          // ... and so does every later stage, over the previous one's outputs
   int32_t micro_cut = 2;          // local levels kept per micro tile of the FIRST stage (0 = keep all)
-  int32_t micro_cut2 = 2;         // the same for the second stage (micro_all only; 0 = keep all): cutting
+  int32_t micro_cut2 = 3;         // the same for the second stage (micro_all only; 0 = keep all; round 4: 3 instead of 2
+                                  // -- the later stages' tiles keep one level more, the top tile one level fewer: QLT::run
+                                  // -0.3 % at 1.5M cells, -2.5 % at the 187.5k-cell shard, profiles/r04_experiments.md 8): cutting
                                   // it moves tree levels from the second to the third stage, which
                                   // otherwise has only a handful of tiles, at no cost in stages
   // How the part of the tree above the ranks' pure subtrees is handled on more than one rank:
