@@ -2709,15 +2709,18 @@ inline int pitch_for (int n) { return (n + 30)/32*32 + 1; }
 // (Round 2, five workgroups per CU: 2048 instead of 3072 -- a 1024-tile stage of 10 chunks then runs 2 workgroups of
 // 5 chunks per tile instead of 4 + 4 + 2: 0.0549 -> 0.0534 ms at 1.5M cells' second stage, 0.0706 -> 0.0695 ms at the
 // shard's first; 5120 and 10240 are slower.)
-constexpr int kSplitUp = 1024, kSplitDown = 2048;  // kSplitDown: micro tiles only
+// (Round 4, later stages cut at three LDS levels: a stage of 1024 tiles is best left unsplit -- its root->leaves launch 0.052 ->
+// 0.048 ms at 1.5M cells, 0.060 -> 0.058 ms as the shard's first stage -- while stages of 128 tiles or fewer want all their chunks
+// in workgroups of their own: kSplitDown is the number of workgroups a launch may GROW to, 1280 = five per CU, rounded down.)
+constexpr int kSplitUp = 1024, kSplitDown = 1280;  // kSplitDown: micro tiles only
 #ifndef CEDR_TAIL_K
 # define CEDR_TAIL_K 5
 #endif
 constexpr int kTailK = CEDR_TAIL_K;
 // (Round 2: splitting the first stage's tiles too -- 9000 or 17000 workgroups wanted -- does not shorten
 // the last, partly idle round: 0.488 -> 0.492 / 0.514 ms.)
-inline int chunk_split (int ntiles, int nchunks, int target) {
-  int y = (target + ntiles - 1)/ntiles;
+inline int chunk_split (int ntiles, int nchunks, int target, bool round_down = false) {
+  int y = round_down ? target/ntiles : (target + ntiles - 1)/ntiles;
   if (y > nchunks) y = nchunks;
   if (y < 1) y = 1;
   const int per = (nchunks + y - 1)/y;  // chunks per workgroup
@@ -2888,7 +2891,7 @@ int cedr_hip_qlt_down_rows (const cedr_hip_qlt_layout* lay, const cedr_hip_stage
       (in_rows ? sizeof(double*)*static_cast<size_t>(lay->l2rndps + lay->nt) : 0);
     if (ldsm > 160*1024) return static_cast<int>(hipErrorInvalidValue);
     static const int split_down = [] { const char* v = std::getenv("CEDR_HIP_SPLIT_DOWN"); return v ? std::atoi(v) : kSplitDown; }();
-    const dim3 gridm(xcd_grid(st->ntiles), chunk_split(st->ntiles, (nt + TTm - 1)/TTm, split_down));
+    const dim3 gridm(xcd_grid(st->ntiles), chunk_split(st->ntiles, (nt + TTm - 1)/TTm, split_down, true));
     auto go = [&] (auto kernel) -> int {
       int e = set_lds_limit(kernel, ldsm);
       if (e) return e;
