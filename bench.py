@@ -211,6 +211,12 @@ def main():
         a.overlap = "start"  # at every N, so that the N = 1 and N > 1 numbers are the same program
     if a.gpus > 1 and "RANK" not in os.environ:
         spawn_ranks(a)  # does not return
+    # The JSON line is the ONLY thing this program writes to its standard output: libraries underneath print there too
+    # (gloo: "[Gloo] Rank 0 is connected to 1 peer ranks ..." at N > 1), so file descriptor 1 is pointed at stderr for the rest
+    # of the run and the line goes out through a duplicate of the original.
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
     import compose_amd as ca
@@ -343,10 +349,14 @@ def main():
             masked = [ca.MaskedStream(w) for w in words]
             keep_streams.append(masked)
             streams = tuple(torch.cuda.ExternalStream(m.handle, device=device) for m in masked)
-        qlt.set_stream(streams[0].cuda_stream)
-        caas.set_stream(streams[1].cuda_stream)
+
+    def use_streams(on):
+        qlt.set_stream(streams[0].cuda_stream if on else None)
+        caas.set_stream(streams[1].cuda_stream if on else None)
         for _, bfb in keep:
-            bfb.set_stream(streams[1].cuda_stream)  # the reducer runs inside caas.run()
+            bfb.set_stream(streams[1].cuda_stream if on else None)  # the reducer runs inside caas.run()
+    if streams and world == 1:
+        use_streams(True)
 
     def barrier():
         if world > 1:
@@ -362,40 +372,88 @@ def main():
             ca.stream_wait_event(streams[1].cuda_stream, down_ev)
         caas.run()
 
-    for _ in range(max(a.warmup, 1) if world > 1 else a.warmup):
-        step()
-    if world > 1:
-        # Fail fast instead of hanging: the first steps over the real transport must complete. (A communicator
-        # whose collectives stall -- a rank that died, an ordering problem across the two streams -- would
-        # otherwise sit in synchronize() until the caller's timeout.)
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(device))
-        evs = [ev]
-        for st in (streams or ()):
-            e2 = torch.cuda.Event()
-            e2.record(st)
-            evs.append(e2)
-        deadline = time.monotonic() + 120.0
-        while not all(e.query() for e in evs):
-            if time.monotonic() > deadline:
-                print("bench.py: rank %d: the warm-up steps did not complete within 120 s over '%s'%s" %
-                      (rank, transport, "; try --serial (one stream)" if streams else ""), file=sys.stderr, flush=True)
-                os._exit(6)
-            time.sleep(0.002)
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-    torch.cuda.synchronize()
-    barrier()
-    t1 = time.perf_counter()
-    dt = t1 - t0
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt[0])
+    def json_head(value_, ms_, nstreams):
+        return {
+            "metric": "cell-tracer-updates/sec (QLT+CAAS), 1.5M cells \u00d7 40 tracers; % HBM roofline",  # BASELINE.json's string
+            "value": value_, "unit": "cell-tracer-updates/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": ms_, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "QLT::run + CAAS::run%s, %d cells x %d cst tracers, balanced 1-D tree, "
+                                   "contiguous %d-way sharding" % (" on two concurrent streams" if nstreams == 2 else "",
+                                                                   ncells, nt, world),
+                       "ncells": ncells, "ntracers": nt, "cells_per_gpu": n,
+                       "transport": transport, "rccl_nranks": world if (world > 1 and a.comm == "rccl") else 0,
+                       "streams": nstreams,
+                       "cu_split": ("CAAS on %d of every 4 groups of 8 CUs, QLT on the rest" % a.cu_split)
+                       if (nstreams == 2 and a.cu_split) else "none",
+                       "caas_reducer": ("bfb_tree_allreduce, %d cells per leaf" % a.caas_bfb) if a.caas_bfb
+                       else "own all-reduce"}}
+
+    def warm_and_check(what, on_stall):
+        """W untimed steps; at N > 1 they must complete (a communicator whose collectives stall -- a rank that died, an
+        ordering problem across the two streams -- would otherwise sit in synchronize() until the caller's timeout)."""
+        for _ in range(max(a.warmup, 1) if world > 1 else a.warmup):
+            step()
+        if world > 1:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(device))
+            evs = [ev]
+            for st in (streams or ()):
+                e2 = torch.cuda.Event()
+                e2.record(st)
+                evs.append(e2)
+            deadline = time.monotonic() + float(os.environ.get("CEDR_BENCH_WARMUP_S", "120"))
+            while not all(e.query() for e in evs):
+                if time.monotonic() > deadline:
+                    print("bench.py: rank %d: the warm-up steps (%s) did not complete in time over '%s'" %
+                          (rank, what, transport), file=sys.stderr, flush=True)
+                    on_stall()
+                time.sleep(0.002)
+
+    def timed_steps():
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            step()
+        torch.cuda.synchronize()
+        barrier()
+        d = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([d], dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            d = float(tt[0])
+        return d
+
+    # N > 1 on two streams: the SAME K steps are first timed on one stream (no cross-stream ordering of the shared
+    # communicator's collectives involved), so that a two-stream run that stalls over a real transport still ends with a
+    # measured line -- flagged as the one-stream program -- instead of no result: every rank's watchdog then prints / exits.
+    dt_one = None
+    watchdog = None
+    if world > 1 and streams:
+        warm_and_check("one stream", lambda: os._exit(6))
+        dt_one = timed_steps()
+
+        def fall_back():
+            if rank == 0:
+                line = json_head(2.0 * ncells * nt / (dt_one / a.steps), 1e3 * dt_one / a.steps, 1)
+                line.update(roofline=None, cpu_baseline=None,
+                            note="the two-stream run (the default program) did not complete over this transport within "
+                                 "its time limit; this is the same K steps back to back on ONE stream, measured before it")
+                print(json.dumps(line), file=json_out, flush=True)
+            os._exit(0)
+        import threading
+        watchdog = threading.Timer(float(os.environ.get("CEDR_BENCH_WATCHDOG_S", "150")), fall_back)
+        watchdog.daemon = True
+        watchdog.start()
+        use_streams(True)
+        if os.environ.get("CEDR_BENCH_SIMULATE_STALL"):  # (test hook: behave like a two-stream run that hangs)
+            time.sleep(1e9)
+        warm_and_check("two streams", fall_back)
+    else:
+        warm_and_check("one stream" if not streams else "two streams", lambda: os._exit(6))
+    dt = timed_steps()
     ms_per_step = 1e3 * dt / a.steps
     value = 2.0 * ncells * nt / (dt / a.steps)
 
@@ -420,14 +478,13 @@ def main():
     # that a kernel's duration is not stretched by a concurrent one.
     if streams:
         torch.cuda.synchronize()
-        qlt.set_stream(None)
-        caas.set_stream(None)
-        for _, bfb in keep:
-            bfb.set_stream(None)
+        use_streams(False)
     # The same K steps back to back on ONE stream (the shape of rounds 1-2, of the CPU baseline and of the
     # roofline leg below), reported next to the two-stream `value` at every N: the two programs differ only in
     # the overlap, so a regression of the cross-stream ordering over real RCCL shows up as a difference here.
-    t_serial = timed(step) if streams else dt / a.steps
+    if watchdog:
+        watchdog.cancel()
+    t_serial = (dt_one / a.steps) if dt_one is not None else (timed(step) if streams else dt / a.steps)
     ca.profile_start()
     for _ in range(a.steps):
         step()
@@ -567,30 +624,17 @@ def main():
                        sample="failed: %r" % (e,))
 
     if rank == 0:
-        line = {
-            "metric": "cell-tracer-updates/sec (QLT+CAAS), 1.5M cells \u00d7 40 tracers; % HBM roofline",  # BASELINE.json's string
-            "value": value, "unit": "cell-tracer-updates/s", "n_gpus": world, "steps": a.steps,
-            "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "QLT::run + CAAS::run%s, %d cells x %d cst tracers, balanced 1-D tree, "
-                                   "contiguous %d-way sharding" % (" on two concurrent streams" if streams else "",
-                                                                   ncells, nt, world),
-                       "ncells": ncells, "ntracers": nt, "cells_per_gpu": n,
-                       "transport": transport, "rccl_nranks": world if (world > 1 and a.comm == "rccl") else 0,
-                       "streams": 2 if streams else 1,
-                       "cu_split": ("CAAS on %d of every 4 groups of 8 CUs, QLT on the rest" % a.cu_split)
-                       if (streams and a.cu_split) else "none",
-                       "caas_reducer": ("bfb_tree_allreduce, %d cells per leaf" % a.caas_bfb) if a.caas_bfb
-                       else "own all-reduce"},
+        line = json_head(value, ms_per_step, 2 if streams else 1)
+        line.update({
             "serial": {"ms_per_step": 1e3 * t_serial, "value": 2.0 * ncells * nt / t_serial,
                        "note": "the same steps with QLT::run and CAAS::run back to back on one stream"},
             "qlt": {"ms_per_run": 1e3 * t_qlt, "updates_per_s": ncells * nt / t_qlt},
             "caas": {"ms_per_run": 1e3 * t_caas, "updates_per_s": ncells * nt / t_caas},
             "pack_unpack": pack, "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu,
-        }
+        })
         if ok is not None:
             line["check_ok"] = ok
-        print(json.dumps(line))
+        print(json.dumps(line), file=json_out, flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

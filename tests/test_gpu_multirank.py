@@ -55,9 +55,9 @@ def test_rccl_point_to_point_group(gpu):
     assert par.exchange([]) == 0
 
 
-def _bench(args, timeout=600):
+def _bench(args, timeout=600, env=None):
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True,
-                         timeout=timeout, cwd=ROOT)
+                         timeout=timeout, cwd=ROOT, env=dict(os.environ, **(env or {})))
     lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
     return res, (json.loads(lines[-1]) if lines else None)
 
@@ -87,6 +87,22 @@ def test_bench_one_gpu_stream_modes(gpu, extra, streams):
                      "--no-cpu-baseline"] + extra)
     assert res.returncode == 0, res.stdout[-1500:] + res.stderr[-1500:]
     assert d["n_gpus"] == 1 and d["check_ok"] is True and d["config"]["streams"] == streams
+
+
+def test_bench_stdout_is_the_json_line_and_a_stalled_two_stream_run_still_reports(gpu):
+    """N > 1: the standard output is exactly ONE line, the JSON (gloo and others print to file descriptor 1 too: it is
+    pointed at stderr), and it carries the same steps' one-stream time next to the two-stream value. A two-stream run that
+    stalls over the transport (test hook) ends, by every rank's watchdog, with the one-stream line measured before it --
+    flagged as such -- and exit code 0 instead of hanging until the caller's timeout."""
+    res, d = _bench(["--gpus", "2", "--comm", "gloo"] + SMALL)
+    assert res.returncode == 0, res.stdout[-1500:] + res.stderr[-1500:]
+    assert len(res.stdout.strip().splitlines()) == 1 and d["config"]["streams"] == 2 and "note" not in d
+    assert d["serial"]["ms_per_step"] > 0 and d["roofline"] is not None
+    res, d = _bench(["--gpus", "2", "--comm", "gloo"] + SMALL, timeout=120,
+                    env={"CEDR_BENCH_SIMULATE_STALL": "1", "CEDR_BENCH_WATCHDOG_S": "6"})
+    assert res.returncode == 0, res.stdout[-1500:] + res.stderr[-1500:]
+    assert len(res.stdout.strip().splitlines()) == 1
+    assert d["n_gpus"] == 2 and d["config"]["streams"] == 1 and "did not complete" in d["note"] and d["value"] > 0
 
 
 def test_bench_under_torch_distributed_run(gpu):
