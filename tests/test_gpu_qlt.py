@@ -1,6 +1,8 @@
 """GPU parity of QLT: the HIP path (through the C ABI) against the CPU oracle on
 the reference's own randomized problems (cedr_test_randomized.cpp), bit for bit,
 plus the reference's property checks with its tolerances."""
+import os
+
 import numpy as np
 import pytest
 
@@ -293,7 +295,9 @@ def test_top_tile_follows_the_lds_the_device_grants(gpu, oracle, limit, max_top_
     want = common.run_oracle_qlt(oracle, (False, False), ncells, 1, _types(trs), v)
     q = common.make_hip_qlt(ca, ca.Tree.make_1d(ncells), ncells, _types(trs))
     tops = [st for st in q.plan()["local"] if st["top"]]
-    if max_top_inputs == 0:
+    if "CEDR_HIP_TOP" in os.environ or "CEDR_HIP_TOP_MAX" in os.environ:
+        pass  # (an env-matrix run that sets the top tile's knobs itself: only the bits are checked)
+    elif max_top_inputs == 0:
         assert not tops
     else:
         assert len(tops) == 1
