@@ -150,6 +150,55 @@ __global__ __launch_bounds__(256, 5) void k_down (const double* __restrict__ l2r
   if (s == 1.2345e-300) out[0] = s;
 }
 
+// (d2) the same with a workgroup taking a PAIR of adjacent tiles per chunk: tile A's rows read, then tile B's, results of both
+// written together at the end of the chunk (2.9 KB contiguous per row and chunk instead of 1.4 KB).
+__global__ __launch_bounds__(256, 5) void k_down_pair (const double* __restrict__ l2r, double* __restrict__ r2l, int64_t stride,
+                                                        int nt, int ncell, int npairs, int64_t out0, double* out) {
+  extern __shared__ double lds[];
+  const int per = gridDim.x >> 3;
+  const int t = (blockIdx.x & 7)*per + (blockIdx.x >> 3);
+  if (t >= npairs) return;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  double s = 0;
+  for (int ch = 0; ch < (nt + 3)/4; ++ch) {
+    int tr = 4*ch + wave; if (tr > nt - 1) tr = nt - 1;
+    double r[2][3];
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      const size_t cell0 = (static_cast<size_t>(2*t + sub))*ncell + 3*lane;
+      double v[3][3];
+#pragma unroll
+      for (int f = 0; f < 3; ++f) {
+        const double* row = l2r + static_cast<size_t>(1 + 4*tr + f)*stride + cell0;
+        const Pair ab = *reinterpret_cast<const Pair*>(row);
+        v[f][0] = ab.x; v[f][1] = ab.y; v[f][2] = row[2];
+      }
+      const double x = r2l[static_cast<size_t>(tr)*stride + out0 + 16*(2*t + sub) + (lane & 15)];
+      r[sub][0] = x; r[sub][1] = x; r[sub][2] = x;
+#pragma unroll
+      for (int f = 0; f < 3; ++f) { r[sub][0] += v[f][0]; r[sub][1] += v[f][1]; r[sub][2] += v[f][2]; }
+      lds[threadIdx.x] = r[sub][0];
+      __syncthreads();
+      r[sub][1] += lds[(threadIdx.x + 64) & 255];
+      __syncthreads();
+      lds[threadIdx.x] = r[sub][1];
+      __syncthreads();
+      r[sub][2] += lds[(threadIdx.x + 128) & 255];
+    }
+    if (3*lane < ncell) {
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub) {
+        double* row = r2l + static_cast<size_t>(tr)*stride + (static_cast<size_t>(2*t + sub))*ncell + 3*lane;
+        Pair ab; ab.x = r[sub][0]; ab.y = r[sub][1];
+        *reinterpret_cast<Pair*>(row) = ab;
+        row[2] = r[sub][2];
+      }
+    }
+    s += r[0][2] + r[1][2];
+  }
+  if (s == 1.2345e-300) out[0] = s;
+}
+
 // (e) the leaves->root sweep's traffic: per chunk of 16 rows a wave reads its 4 rows, and the
 // workgroup writes one 128-byte line per row -- the tile's 16 outputs -- to slot out0 + 16 t of that row. WRITE 0: no stores;
 // 2: the tile's lines as one contiguous block [tile][row][16] in a separate buffer instead.
@@ -277,6 +326,7 @@ int main () {
     CK(hipMalloc(&blk, static_cast<size_t>(ntiles)*nfields*16*8));
     const double db = static_cast<double>(ntiles)*ncell*(32.0*nt + 8);
     timeit("root->leaves traffic: 3 rows read + 1 written per tracer, 5 WGs/CU", db, [&] { hipLaunchKernelGGL(k_down<1>, dim3(8192), dim3(256), 28*1024, 0, d, r2l, stride, nt, ncell, ntiles, static_cast<int64_t>(ncells), out); });
+    timeit("root->leaves traffic, a PAIR of tiles per workgroup (4096 WGs), results written together", db, [&] { hipLaunchKernelGGL(k_down_pair, dim3(4096), dim3(256), 28*1024, 0, d, r2l, stride, nt, ncell, ntiles/2, static_cast<int64_t>(ncells), out); });
     timeit("root->leaves traffic, results as contiguous 16-B pieces via LDS", db, [&] { hipLaunchKernelGGL(k_down<2>, dim3(8192), dim3(256), 28*1024, 0, d, r2l, stride, nt, ncell, ntiles, static_cast<int64_t>(ncells), out); });
     timeit("root->leaves traffic, results IN PLACE over the 'orig' row just read", db, [&] { hipLaunchKernelGGL(k_down<3>, dim3(8192), dim3(256), 28*1024, 0, d, r2l, stride, nt, ncell, ntiles, static_cast<int64_t>(ncells), out); });
     timeit("root->leaves traffic, results into the tracer's 4th row of l2r", db, [&] { hipLaunchKernelGGL(k_down<4>, dim3(8192), dim3(256), 28*1024, 0, d, r2l, stride, nt, ncell, ntiles, static_cast<int64_t>(ncells), out); });
