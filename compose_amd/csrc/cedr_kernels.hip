@@ -98,19 +98,21 @@ __device__ __forceinline__ WorkItem work_item (const int ntiles, const TailSplit
 #endif
   return w;
 }
-inline unsigned xcd_grid_tail (const int ntiles, const TailSplit tail) {
-#if CEDR_XCD_REMAP
-  const int per = (ntiles + 7)/8;
-  if (tail.k > 1 && tail.nf < per) return 8u*static_cast<unsigned>(tail.nf + (per - tail.nf)*tail.k);
-#endif
-  return 8u*static_cast<unsigned>((ntiles + 7)/8);
-}
 inline unsigned xcd_grid (const int ntiles) {
 #if CEDR_XCD_REMAP
   return 8u*static_cast<unsigned>((ntiles + 7)/8);
 #else
   return static_cast<unsigned>(ntiles);
 #endif
+}
+inline unsigned xcd_grid_tail (const int ntiles, const TailSplit tail) {
+#if CEDR_XCD_REMAP
+  const int per = (ntiles + 7)/8;
+  if (tail.k > 1 && tail.nf < per) return 8u*static_cast<unsigned>(tail.nf + (per - tail.nf)*tail.k);
+#else
+  (void) tail;
+#endif
+  return xcd_grid(ntiles);
 }
 
 // Diagnostic builds only (wrong results): -DCEDR_DIAG_L2 makes every tile read its cell records from
