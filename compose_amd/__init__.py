@@ -143,6 +143,8 @@ _SIGS = {
     "cedr_caas_set_Qm_source": (C.c_int, [_vp, _vp]),
     "cedr_caas_get_device_op": (C.c_int, [_vp, C.POINTER(_CaasDeviceOp)]),
     "cedr_caas_get_recv": (C.c_int, [_vp, C.POINTER(_vp)]),
+    "cedr_caas_create_bfb": (_vp, [_vp, C.c_int, _vp, C.c_int]),
+    "cedr_caas_fused_with_bfb": (C.c_int, [_vp]),
     "cedr_bfb_create": (_vp, [_vp, _vp, C.c_int, C.c_int]),
     "cedr_bfb_free": (None, [_vp]),
     "cedr_bfb_nlocal": (C.c_int, [_vp]),
@@ -217,6 +219,13 @@ def _handle(h, what):
 
 def device_count():
     return lib().cedr_device_count()
+
+
+def kernels_sha256():
+    """sha256 of the cedr_kernels.hip the loaded library was built from (stamped in at build time)."""
+    f = lib().cedr_hip_kernels_sha256
+    f.restype = C.c_char_p
+    return f().decode()
 
 
 class MaskedStream:
@@ -762,11 +771,19 @@ class CAAS(_CDR):
 
     user_reducer(send_ptr, recv_ptr, nlocal, nfld) -> int mirrors
     CAAS::UserAllReducer::operator() (cedr_caas.hpp:31-40) on device pointers.
+    user_reducer may also be a BfbTreeAllReducer object: the production pairing as a type
+    (caas::BfbUserAllReducer), which run() fuses with the reducer's first tree stage.
     """
     _pfx = "cedr_caas_"
 
     def __init__(self, parallel, nlclcells, user_reducer=None, n_accum_in_place=1):
         self.p = parallel
+        self.n = int(nlclcells)
+        if isinstance(user_reducer, BfbTreeAllReducer):
+            self._bfb = user_reducer  # shared with the C++ object; kept alive here as well
+            self.h = _handle(lib().cedr_caas_create_bfb(parallel.h, self.n, user_reducer.h,
+                                                        int(n_accum_in_place)), "CAAS")
+            return
         if user_reducer is not None:
             self._cb = USER_ALLREDUCE_FN(lambda user, s, r, nl, nf: int(user_reducer(s, r, nl, nf) or 0))
         else:
@@ -774,6 +791,10 @@ class CAAS(_CDR):
         self.h = _handle(lib().cedr_caas_create(parallel.h, int(nlclcells), self._cb,
                                                 int(n_accum_in_place), None), "CAAS")
         self.n = int(nlclcells)
+
+    def fused_with_bfb(self):
+        """After finish_setup: whether run() fuses the reduce pass with the BFB reducer's first stage."""
+        return bool(lib().cedr_caas_fused_with_bfb(self.h))
 
     def get_device_op(self):
         op = _CaasDeviceOp()

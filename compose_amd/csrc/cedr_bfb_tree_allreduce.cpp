@@ -1,5 +1,6 @@
 #include "cedr_bfb_tree_allreduce.hpp"
 
+#include <algorithm>
 #include <cstdlib>
 #include <memory>
 #include <vector>
@@ -31,6 +32,11 @@ struct BfbTreeAllReducerHip::Impl {
   struct RowTable { const Real* send = nullptr; std::unique_ptr<dev::Buffer<const Real*> > rows; };
   std::vector<RowTable> tables;
   size_t next_evict = 0;
+  // For CAAS fused with this reducer (first_stage_for_fusion): leaves under every tile of the first local stage
+  // and whether those tiles cover the local leaves 0 .. nlocal-1 exactly once, in leaf order.
+  dev::Buffer<int32_t> tile_nleaves;
+  int32_t max_tile_leaves = 0;
+  bool fusable = false;
 };
 
 void BfbTreeAllReducerHip::init (const mpi::Parallel::Ptr& p, const tree::FlatTree& tree,
@@ -79,6 +85,70 @@ void BfbTreeAllReducerHip::finish_setup () {
   m_->root_slot.upload(std::vector<int32_t>(1, eng_->get_plan().root_slot));
   m_->op.upload(std::vector<uint8_t>(nfield_, 0));
   eng_->set_all_sums(true);  // every field is a sum (0 + kid0 + kid1: the zero-init flavour of the sum kernels)
+  // May a caller's kernel sweep the first stage itself? Micro tiles whose leaves are the local leaves in order,
+  // every local leaf under exactly one tile (a leaf that is itself a rank's boundary root is under none).
+  const plan::Plan& pl = eng_->get_plan();
+  if (m_->identity && eng_->first_stage_takes_rows() && ! pl.local.empty() && ! pl.local[0].top) {
+    const plan::Stage& st = pl.local[0];
+    std::vector<int32_t> nl(st.tiles.size());
+    int64_t next = 0;
+    bool ok = true;
+    for (size_t t = 0; t < st.tiles.size() && ok; ++t) {
+      const plan::Tile& tl = st.tiles[t];
+      if (tl.nleaf < 1 || tl.in0 != next) { ok = false; break; }
+      int32_t covered = 0;  // the micro-subtrees of a tile follow each other without gaps
+      for (int32_t i = 0; i < tl.nleaf && ok; ++i) {
+        const uint16_t dl = st.micro[tl.micro_off + i];
+        const int shape = dl >> 8;
+        if ((dl & 0xff) != covered) ok = false;
+        covered += shape == 0 ? 1 : (shape == 1 ? 2 : 3);
+      }
+      nl[t] = covered;
+      next += nl[t];
+      m_->max_tile_leaves = std::max(m_->max_tile_leaves, nl[t]);
+    }
+    if (ok && next == nlocal_) {
+      m_->tile_nleaves.upload(nl);
+      m_->fusable = true;
+    }
+  }
+}
+
+bool BfbTreeAllReducerHip::first_stage_for_fusion (FirstStage& fs) const {
+  if ( ! m_->bd.size()) const_cast<BfbTreeAllReducerHip*>(this)->finish_setup();
+  if ( ! m_->fusable) return false;
+  fs.stage = &eng_->local_stages()[0]->h;
+  fs.tile_nleaves = m_->tile_nleaves.data();
+  fs.max_tile_leaves = m_->max_tile_leaves;
+  fs.stride = eng_->stride();
+  fs.data = m_->bd.data();
+  return true;
+}
+
+void BfbTreeAllReducerHip::allreduce_after_first_stage (Real* recv, hipStream_t s) const {
+  cedr_throw_if( ! m_->fusable, "allreduce_after_first_stage: this reducer's first stage cannot be fused");
+  finish(nullptr, recv, s, true);
+}
+
+// Everything after the leaf fill: the local stages (from the second if first_done), the exchange, the top.
+void BfbTreeAllReducerHip::finish (const Real* const* in_rows, Real* recv, hipStream_t s, const bool first_done) const {
+  Real* const bd = m_->bd.data();
+  const int64_t S = eng_->stride();
+  // Every node is 0 + kid0 + kid1, as in cedr_bfb_tree_allreduce.cpp:117-123.
+  if (eng_->has_apex()) {  // multi-rank, small replicated top: one launch after the all-gather
+    const Real* const gathered = eng_->up_to_exchange(nfield_, m_->op.data(), bd, true, s, in_rows, first_done);
+    cedr_k_check(cedr_hip_tree_apex_sum(eng_->apex_stage(), gathered, eng_->apex_src(), nfield_, 1, recv, s));
+    return;
+  }
+  if (eng_->takes_root_out()) {  // one rank: the top tile's launch writes the root's record to recv itself
+    eng_->up(nfield_, m_->op.data(), bd, true, s, in_rows, false, recv, first_done);
+    return;
+  }
+  eng_->up(nfield_, m_->op.data(), bd, true, s, in_rows, false, nullptr, first_done);
+  eng_->bcast_root(nfield_, bd, s);  // level mode only: cedr_bfb_tree_allreduce.cpp:68-76, the way back down
+  // The root's record is the result on every rank (:68-76 read it back from
+  // the first leaf after the root->leaves copies; the value is the same).
+  cedr_k_check(cedr_hip_gather_slots(bd, S, nfield_, m_->root_slot.data(), 1, recv, s));
 }
 
 void BfbTreeAllReducerHip::allreduce (const Real* send, Real* recv, const bool transpose) const {
@@ -111,21 +181,7 @@ void BfbTreeAllReducerHip::allreduce (const Real* send, Real* recv, const bool t
   } else {
     cedr_k_check(cedr_hip_scatter_slots(bd, S, nfield_, m_->leaf_slots.data(), nlocal_, send, s));
   }
-  // Every node is 0 + kid0 + kid1, as in cedr_bfb_tree_allreduce.cpp:117-123.
-  if (eng_->has_apex()) {  // multi-rank, small replicated top: one launch after the all-gather
-    const Real* const gathered = eng_->up_to_exchange(nfield_, m_->op.data(), bd, true, s, in_rows);
-    cedr_k_check(cedr_hip_tree_apex_sum(eng_->apex_stage(), gathered, eng_->apex_src(), nfield_, 1, recv, s));
-    return;
-  }
-  if (eng_->takes_root_out()) {  // one rank: the top tile's launch writes the root's record to recv itself
-    eng_->up(nfield_, m_->op.data(), bd, true, s, in_rows, false, recv);
-    return;
-  }
-  eng_->up(nfield_, m_->op.data(), bd, true, s, in_rows);
-  eng_->bcast_root(nfield_, bd, s);  // level mode only: cedr_bfb_tree_allreduce.cpp:68-76, the way back down
-  // The root's record is the result on every rank (:68-76 read it back from
-  // the first leaf after the root->leaves copies; the value is the same).
-  cedr_k_check(cedr_hip_gather_slots(bd, S, nfield_, m_->root_slot.data(), 1, recv, s));
+  finish(in_rows, recv, s, false);
 }
 
 }  // namespace cedr

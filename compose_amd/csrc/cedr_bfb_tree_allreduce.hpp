@@ -9,6 +9,7 @@
 
 #include <memory>
 
+#include "../../include/cedr_hip.h"
 #include "cedr_tree.hpp"
 
 typedef struct ihipStream_t* hipStream_t;
@@ -37,7 +38,22 @@ public:
   void allreduce(const Real* send, Real* recv, const bool transpose = false) const;
 
   Int nlocal () const { return nlocal_; }
+  Int nfield () const { return nfield_; }
   void set_stream(hipStream_t stream);
+
+  // ---- additions of this build: the reducer's first stage swept by the CALLER's kernel ----
+  // CAAS paired with this reducer (caas::BfbUserAllReducer) forms its per-group partial sums and the first
+  // leaves->root stage of this tree in one kernel (cedr_hip_caas_reduce_local_bfb), so the partial sums never reach
+  // HBM. first_stage_for_fusion: false if the tree does not allow it (the local leaves are not the first stage's
+  // inputs in order: tiny trees, a leaf that is a rank boundary by itself, non-contiguous leaf order); otherwise
+  // the stage, the leaves under each of its tiles (device array), their maximum, and where the tiles' outputs go:
+  // data[field*stride + slot]. allreduce_after_first_stage: the rest of allreduce() once that kernel has run on
+  // 'stream' (further stages, the exchange between ranks, the top), recv as in allreduce.
+  struct FirstStage {
+    const cedr_hip_stage* stage; const int32_t* tile_nleaves; int32_t max_tile_leaves; int64_t stride; Real* data;
+  };
+  bool first_stage_for_fusion(FirstStage& fs) const;
+  void allreduce_after_first_stage(Real* recv, hipStream_t stream) const;
 
 private:
   struct Impl;
@@ -48,6 +64,7 @@ private:
   std::unique_ptr<Impl> m_;
   void init(const mpi::Parallel::Ptr& p, const tree::FlatTree& tree, const Int nleaf,
             const Int nfield);
+  void finish(const Real* const* in_rows, Real* recv, hipStream_t s, bool first_done) const;
 };
 
 template <typename ExeSpace = cedr::Hip> using BfbTreeAllReducer = BfbTreeAllReducerHip;

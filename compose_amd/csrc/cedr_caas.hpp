@@ -20,6 +20,7 @@ typedef int MPI_Op;
 #endif
 
 namespace cedr {
+class BfbTreeAllReducerHip;
 namespace caas {
 
 class CAASHip : public CDR {
@@ -86,6 +87,8 @@ public:
   void bind_arrays(Real* Qm, const Real* Qm_min, const Real* Qm_max, const Real* Qm_prev);
   const Real* send_data () const;
   const Real* recv_data () const;
+  // Whether run() takes the fused CAAS + BFB reducer path (decided in finish_setup).
+  bool fused_with_bfb_reducer () const;
 
   // Exposed for tests: the three steps of run(), reference cedr_caas.cpp:129-253.
   void reduce_locally();
@@ -106,6 +109,25 @@ private:
 };
 
 template <typename ExeSpace = cedr::Hip> using CAAS = CAASHip;
+
+// THE PRODUCTION PAIRING as a type: a UserAllReducer that hands CAAS's per-group partial sums
+// (cedr_caas.cpp:137-168: send(field, group), i.e. the reducer's transposed layout) to this library's
+// BfbTreeAllReducer (cedr_bfb_tree_allreduce.cpp:79-159) -- what a host model writes by hand around the
+// reference. Used through operator() it is exactly that; but a CAAS that finds this type as its reducer
+// fuses its reduce pass with the first stage of the reducer's tree (cedr_hip_caas_reduce_local_bfb): the
+// partial sums stay on chip, same bits. CEDR_HIP_CAAS_BFB_FUSE=0 keeps the two separate launches.
+// The reducer's leaf i must be the group of cells [i*n_accum_in_place, (i+1)*n_accum_in_place) and it must
+// reduce 4*nt fields; any other tree / leaf order still works, unfused.
+struct BfbUserAllReducer : public CAASHip::UserAllReducer {
+  BfbUserAllReducer(const std::shared_ptr<BfbTreeAllReducerHip>& bfb, int n_accum_in_place);
+  int operator()(const mpi::Parallel& p, Real* sendbuf, Real* rcvbuf, int nlocal, int nfld,
+                 MPI_Op op) const override;
+  int n_accum_in_place () const override { return nacc_; }
+  const std::shared_ptr<BfbTreeAllReducerHip>& reducer () const { return bfb_; }
+private:
+  std::shared_ptr<BfbTreeAllReducerHip> bfb_;
+  int nacc_;
+};
 
 }  // namespace caas
 }  // namespace cedr

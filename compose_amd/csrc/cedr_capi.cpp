@@ -27,7 +27,7 @@ struct TreeBox { tree::FlatTree t; };
 struct NsBox { tree::NodeSets::ConstPtr owned; const tree::NodeSets* ns; };
 struct PlanBox { plan::Plan owned; const plan::Plan* p; int64_t stride; };
 struct QltBox { std::unique_ptr<qlt::QLTHip> q; NsBox ns; PlanBox plan; };
-struct BfbBox { std::unique_ptr<BfbTreeAllReducerHip> b; };
+struct BfbBox { std::shared_ptr<BfbTreeAllReducerHip> b; };
 
 struct CbReducer : public caas::CAASHip::UserAllReducer {
   cedr_user_allreduce_fn fn; int nacc; void* user;
@@ -403,6 +403,17 @@ void* cedr_caas_create (void* parallel, int nlclcells, cedr_user_allreduce_fn re
   return b;
   CEDR_CATCH(nullptr)
 }
+void* cedr_caas_create_bfb (void* parallel, int nlclcells, void* bfb, int nacc) {
+  CEDR_TRY
+  cedr_throw_if( ! bfb, "cedr_caas_create_bfb needs a BfbTreeAllReducer handle");
+  caas::CAASHip::UserAllReducer::Ptr r =
+    std::make_shared<caas::BfbUserAllReducer>(static_cast<BfbBox*>(bfb)->b, nacc);
+  CaasBox* b = new CaasBox();
+  b->c.reset(new caas::CAASHip(static_cast<ParallelBox*>(parallel)->p, nlclcells, r));
+  return b;
+  CEDR_CATCH(nullptr)
+}
+int cedr_caas_fused_with_bfb (void* h) { return CA(h).fused_with_bfb_reducer() ? 1 : 0; }
 void cedr_caas_free (void* h) { delete static_cast<CaasBox*>(h); }
 int cedr_caas_declare_tracer (void* h, int pt, int rhomidx) {
   CEDR_TRY CA(h).declare_tracer(pt, rhomidx); return 0; CEDR_CATCH(-1)

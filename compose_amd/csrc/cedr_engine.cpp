@@ -208,10 +208,12 @@ bool TreeEngine::first_stage_takes_rows () const {
 // boundary roots' records into sendbuf_ (the gather launch fused in).
 void TreeEngine::up_local (int32_t nfields, const uint8_t* op_dev, double* data, bool zero_init,
                            hipStream_t stream, const double* const* in_rows, bool skip_top, bool pack_roots,
-                           double* root_out) {
+                           double* root_out, bool first_done) {
   cedr_throw_if( ! uploaded_, "TreeEngine::upload was not called");
   for (size_t i = 0; i < local_.size(); ++i) {
-    if (plan_.local[i].top) {
+    if (i == 0 && first_done) {
+      // (the caller's own kernel swept the first stage: its tile outputs are in 'data' already)
+    } else if (plan_.local[i].top) {
       if (skip_top) continue;
       if (root_out)  // single rank: the root's record straight to the caller's buffer
         cedr_k_check(cedr_hip_tree_top_up(&local_[i]->h, &local_[i]->tile0, nfields, op_dev, stride_, data, zero_init,
@@ -268,11 +270,13 @@ float TreeEngine::time_first_stage_down (const cedr_hip_qlt_layout* lay, double*
 }
 
 void TreeEngine::up (int32_t nfields, const uint8_t* op_dev, double* data, bool zero_init,
-                     hipStream_t stream, const double* const* in_rows, bool skip_top, double* root_out) {
+                     hipStream_t stream, const double* const* in_rows, bool skip_top, double* root_out,
+                     bool first_done) {
   const bool xch = ! plan_.level_mode && ! top_.empty();
   if (xch) size_exchange_buffers(nfields);
   cedr_throw_if(root_out && ! takes_root_out(), "root_out needs a single-rank plan with a fused top tile");
-  up_local(nfields, op_dev, data, zero_init, stream, in_rows, skip_top, xch && has_top(), root_out);
+  cedr_throw_if(first_done && (local_.empty() || plan_.local[0].top), "first_done needs a first stage of tiles");
+  up_local(nfields, op_dev, data, zero_init, stream, in_rows, skip_top, xch && has_top(), root_out, first_done);
   if (plan_.level_mode) { up_levels(nfields, op_dev, data, zero_init, stream); return; }
   if (top_.empty()) return;
   exchange(nfields, data, stream, has_top());
@@ -324,10 +328,11 @@ void TreeEngine::exchange (int32_t nfields, double* data, hipStream_t stream, bo
 
 const double* TreeEngine::up_to_exchange (int32_t nfields, const uint8_t* op_dev, double* data,
                                           bool zero_init, hipStream_t stream,
-                                          const double* const* in_rows) {
+                                          const double* const* in_rows, bool first_done) {
   cedr_throw_if( ! uploaded_ || ! apex_, "up_to_exchange needs an uploaded plan with an apex tile");
+  cedr_throw_if(first_done && (local_.empty() || plan_.local[0].top), "first_done needs a first stage of tiles");
   size_exchange_buffers(nfields);
-  up_local(nfields, op_dev, data, zero_init, stream, in_rows, false, has_top());
+  up_local(nfields, op_dev, data, zero_init, stream, in_rows, false, has_top(), nullptr, first_done);
   exchange(nfields, data, stream, has_top());
   return recvbuf_.data();
 }

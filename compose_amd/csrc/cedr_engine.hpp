@@ -58,9 +58,11 @@ public:
   // rank: cedr_hip_qlt_top mode 1 re-forms the tile's sums and computes the root in its one launch).
   // root_out (device, nfields doubles; single rank with a fused top tile only -- see takes_root_out()): the
   // top tile's launch also writes the root's record there, which saves the caller a gather launch.
+  // first_done: the caller's own kernel has swept the first local stage already -- its tiles' outputs are in
+  // data (CAAS fused with the BFB reducer, cedr_hip_caas_reduce_local_bfb); the sweep starts at the second.
   void up(int32_t nfields, const uint8_t* op_dev, double* data, bool zero_init,
           hipStream_t stream, const double* const* in_rows = nullptr, bool skip_top = false,
-          double* root_out = nullptr);
+          double* root_out = nullptr, bool first_done = false);
   bool takes_root_out () const { return has_top() && plan_.nranks == 1 && ! plan_.level_mode; }
   // Milliseconds the first local leaves->root stage takes over 'data' (best of three launches; it only sums, and
   // writes the stage's tile-output slots of data), or a negative value when that stage is too small for the answer
@@ -86,7 +88,8 @@ public:
   // (cedr_hip_qlt_apex / cedr_hip_tree_apex_sum), which do the rest in one launch.
   bool has_apex () const { return apex_ != nullptr; }
   const double* up_to_exchange(int32_t nfields, const uint8_t* op_dev, double* data, bool zero_init,
-                               hipStream_t stream, const double* const* in_rows = nullptr);
+                               hipStream_t stream, const double* const* in_rows = nullptr,
+                               bool first_done = false);
   const cedr_hip_stage* apex_stage () const { return &apex_->h; }
   const int32_t* apex_src () const { return apex_src_.data(); }       // record of every apex input
   const int32_t* apex_my_in () const { return apex_my_in_.data(); }   // apex inputs that are my roots
@@ -124,7 +127,8 @@ private:
   void exchange(int32_t nfields, double* data, hipStream_t stream, bool gathered = false);
   void size_exchange_buffers(int32_t nfields);
   void up_local(int32_t nfields, const uint8_t* op_dev, double* data, bool zero_init, hipStream_t stream,
-                const double* const* in_rows, bool skip_top, bool pack_roots, double* root_out = nullptr);
+                const double* const* in_rows, bool skip_top, bool pack_roots, double* root_out = nullptr,
+                bool first_done = false);
   struct StepOff { size_t nodes, outs, ins; };
   std::vector<StepOff> lvl_off_;
   dev::Buffer<int32_t> lvl_nodes_, lvl_outs_, lvl_ins_;

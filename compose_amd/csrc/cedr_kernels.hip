@@ -2447,6 +2447,9 @@ constexpr int kAccumSub = CEDR_CAAS_ACCUM_SUB;  // cells per sub-block (upper bo
 # define CEDR_CAAS_ACCUM_NSB 1
 #endif
 constexpr int kAccumNsb = CEDR_CAAS_ACCUM_NSB;     // sub-blocks per workgroup
+constexpr size_t kBfbFusedMaxLds = 80*1024;        // caas_reduce_bfb_kernel: at least two workgroups per CU
+constexpr int kBfbFusedWgs = 8192;                 // ... workgroups wanted per launch (tracers are dealt to reach it)
+constexpr int kBfbFusedWgsP2 = 16384;              // the same for caas_reduce_bfb_p2_kernel
 template <int VEC>  // 2: 16-byte accesses, two cells per thread and pass (needs n and sb even, 16-byte aligned rows)
 __global__ __launch_bounds__(kBlock)
 void caas_reduce_accum_lds_kernel (const int32_t* __restrict__ probs, const int nt, const int n,
@@ -2514,6 +2517,387 @@ void caas_reduce_accum_lds_kernel (const int32_t* __restrict__ probs, const int 
       send[static_cast<size_t>(nacc)*(q*nt + k) + g0 + g] = acc;
     }
     __syncthreads();
+  }
+}
+
+// THE PRODUCTION PAIRING, FUSED. CAAS whose UserAllReducer is this library's BFB tree reducer
+// (caas::BfbUserAllReducer): reference cedr_caas.cpp:137-168 emits one partial sum per (field, group of
+// n_accum cells) -- 32/n_accum bytes per cell-tracer written to HBM -- and cedr_bfb_tree_allreduce.cpp:91-124
+// reads them all back as the leaves of its tree. Here the workgroup that clips the cells under one FIRST-STAGE
+// TILE of the reducer's tree (micro tile: <= 64 micro-subtrees of <= 3 leaves, leaf = group) also forms the
+// group sums (0 + c0 + c1 + ... in the reference's order), the micro-subtrees and the tile's LDS levels
+// (0 + kid0 + kid1, cedr_bfb_tree_allreduce.cpp:117-123) and writes only the tile's outputs into the reducer's
+// field-major buffer bd: no partial-sum buffer, no first leaves->root launch. Same operands in the same order
+// as the two separate kernels, so the bits are the same.
+// grid = (tiles dealt to XCDs, nt). The cells of a tile (nl leaves x na cells, contiguous: the reducer's leaf
+// order is the cell-group order) are streamed like caas_reduce_kernel does; {clip, term, min, max} are parked
+// in LDS (row q, cell i at i + (i >> sh): a power-of-two skew that keeps the group-strided reads of the second
+// phase off one bank); after ONE workgroup barrier wave q owns quantity q: lane i sums the groups of
+// micro-subtree i, combines them in registers and walks the tile's LDS levels alone (a wave's LDS accesses
+// execute in order: no further barrier). Field of (quantity q, tracer k) = q*nt + k, CAAS's send order.
+// NP > 0: every tile has at most 256*VEC*NP cells -- all of a thread's loads are issued before the first use.
+// A workgroup takes 'tper' consecutive tracers of its tile (blockIdx.y-th share) and, in the NP > 0 builds, has the
+// NEXT tracer's loads in flight while it clips, parks and sums the current one: a workgroup's life is otherwise
+// descriptor fetch -> stream loads -> LDS phase -> tree, with loads in flight for a third of it, and at the 4-5
+// workgroups a CU's LDS holds that leaves too few bytes in flight to fill the memory system (first version, one
+// tracer per workgroup: 0.474 ms for the 2.4 GB of the 1.5M x 40 case, against 0.384 ms for caas_reduce_kernel).
+template <int VEC, int NP>
+__global__ __launch_bounds__(kBlock)
+void caas_reduce_bfb_kernel (const int32_t* __restrict__ probs, const int nt, const int n,
+                             const int need_conserve, const int na, const int sh,
+                             double* __restrict__ d, const double* __restrict__ qm_src,
+                             const cedr_hip_stage st, const int32_t* __restrict__ tile_nl,
+                             const int64_t stride, double* __restrict__ bd, const int rowlen,
+                             const int pitch, const int tper) {
+  extern __shared__ double lds[];
+  const int tix = xcd_tile(st.ntiles);
+  if (tix < 0) return;
+  const int k0 = blockIdx.y*tper, k1 = min(nt, k0 + tper);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & (kWave - 1);
+  const cedr_hip_tile tile = st.tiles[tix];
+  const int nl = tile_nl[tix];
+  uint32_t* const kidsL = reinterpret_cast<uint32_t*>(lds);
+  int32_t* const lvlL = reinterpret_cast<int32_t*>(kidsL + st.max_nint);
+  int32_t* const outL = reinterpret_cast<int32_t*>(lds + (st.max_nint + 1));
+  double* const v = lds + (st.max_nint + 1) + kWave/2;
+  double* const park = v + static_cast<size_t>(kNW)*pitch;
+  const size_t N = n;
+#ifdef CEDR_DIAG_BFB_GEOM  // (diagnostic builds, wrong results: every workgroup streams CEDR_DIAG_BFB_GEOM cells, back to back)
+  const int64_t cell0 = static_cast<int64_t>(tix)*CEDR_DIAG_BFB_GEOM;
+  const int cnt = CEDR_DIAG_BFB_GEOM + 0*nl;
+#else
+  const int64_t cell0 = static_cast<int64_t>(tile.in0)*na;
+  const int cnt = nl*na;
+#endif
+  typedef double __attribute__((ext_vector_type(2))) d2;
+  // rows of tracer k, at the tile's first cell
+  auto row_qm = [&] (const int k) { return d + (1 + k)*N + cell0; };
+  auto row_in = [&] (const int k) { return qm_src ? qm_src + k*N + cell0 : d + (1 + k)*N + cell0; };
+  auto row_lo = [&] (const int k) { return d + (1 + nt + k)*N + cell0; };
+  auto row_hi = [&] (const int k) { return d + (1 + 2*static_cast<size_t>(nt) + k)*N + cell0; };
+  auto row_pv = [&] (const int k) -> const double* {
+    return (need_conserve && (probs[k] & CONSERVE) != 0) ? d + (1 + 3*static_cast<size_t>(nt) + k)*N + cell0 : nullptr;
+  };
+  auto park2 = [&] (const int i, const d2 cl, const d2 term, const d2 lo, const d2 hi) {
+    const int j0 = i + (i >> sh), j1 = (i + 1) + ((i + 1) >> sh);
+    park[j0] = cl.x; park[j1] = cl.y;
+    park[rowlen + j0] = term.x; park[rowlen + j1] = term.y;
+    park[2*rowlen + j0] = lo.x; park[2*rowlen + j1] = lo.y;
+    park[3*rowlen + j0] = hi.x; park[3*rowlen + j1] = hi.y;
+  };
+  auto park1 = [&] (const int i, const double cl, const double term, const double lo, const double hi) {
+    const int j = i + (i >> sh);
+    park[j] = cl; park[rowlen + j] = term; park[2*rowlen + j] = lo; park[3*rowlen + j] = hi;
+  };
+  constexpr int NPR = NP > 0 ? NP : 1;
+  struct Regs { d2 q[NPR], lo[NPR], hi[NPR], pv[NPR]; };
+  const int cnt2 = cnt >> 1;
+  auto load = [&] (const int k, Regs& r) {  // (VEC == 2, NP > 0)
+    const d2* __restrict__ vin = reinterpret_cast<const d2*>(row_in(k));
+    const d2* __restrict__ vlo = reinterpret_cast<const d2*>(row_lo(k));
+    const d2* __restrict__ vhi = reinterpret_cast<const d2*>(row_hi(k));
+    const d2* __restrict__ vpv = reinterpret_cast<const d2*>(row_pv(k));
+    // Inline-asm loads: the compiler does not count them, so it cannot make the current tracer's work wait for them
+    // (with ordinary loads it waited with vmcnt(4..0) at the first use of the PREVIOUS loads' registers, i.e. for the
+    // prefetch as well -- vmcnt retires in order); wait_regs() is the matching wait. UNCONDITIONAL: threads past the
+    // tile's last cell pair re-read it; a tracer without Qm_prev re-reads its Qm row (cache hits).
+#pragma unroll
+    for (int p = 0; p < NPR; ++p) {
+      const int i2 = min(static_cast<int>(threadIdx.x) + kBlock*p, cnt2 - 1);
+      asm volatile("global_load_dwordx4 %0, %1, off nt" : "=&v"(r.q[p]) : "v"(vin + i2) : "memory");
+      asm volatile("global_load_dwordx4 %0, %1, off nt" : "=&v"(r.lo[p]) : "v"(vlo + i2) : "memory");
+      asm volatile("global_load_dwordx4 %0, %1, off nt" : "=&v"(r.hi[p]) : "v"(vhi + i2) : "memory");
+      asm volatile("global_load_dwordx4 %0, %1, off nt" : "=&v"(r.pv[p]) : "v"((vpv ? vpv : vin) + i2) : "memory");
+    }
+  };
+  auto wait_regs = [&] (Regs& r) {
+    if constexpr (NPR == 1)
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(r.q[0]), "+v"(r.lo[0]), "+v"(r.hi[0]), "+v"(r.pv[0]) :: "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(r.q[0]), "+v"(r.lo[0]), "+v"(r.hi[0]), "+v"(r.pv[0]),
+                   "+v"(r.q[NPR-1]), "+v"(r.lo[NPR-1]), "+v"(r.hi[NPR-1]), "+v"(r.pv[NPR-1]) :: "memory");
+  };
+  // clip (cedr_caas_inl.hpp:45-57), write Qm back, park {clip, term, min, max} of this thread's cells
+  auto clip_park = [&] (const int k, const Regs& r) {
+    d2* __restrict__ vout = reinterpret_cast<d2*>(row_qm(k));
+    const bool has_pv = row_pv(k) != nullptr;
+    (void) has_pv;
+#pragma unroll
+    for (int p = 0; p < NPR; ++p) {
+      const int i2 = threadIdx.x + kBlock*p;
+      if (i2 < cnt2) {
+        d2 cl;
+        cl.x = rmin(r.hi[p].x, rmax(r.lo[p].x, r.q[p].x));
+        cl.y = rmin(r.hi[p].y, rmax(r.lo[p].y, r.q[p].y));
+#ifndef CEDR_DIAG_BFB_NOCLIPSTORE  // (diagnostic builds, wrong results: parts of the kernel left out)
+        vout[i2] = cl;
+#endif
+#ifndef CEDR_DIAG_BFB_NOPARK
+        park2(2*i2, cl, r.pv[p], r.lo[p], r.hi[p]);  // (pv holds Qm itself for a tracer without Qm_prev)
+#else
+        if (cl.x + cl.y + r.pv[p].x + r.lo[p].x + r.hi[p].y == 1.2345e-300) park[0] = 0;
+#endif
+      }
+    }
+  };
+  auto clip_park_loop = [&] (const int k) {  // (any tile size, 16- or 8-byte accesses; nothing in flight across tracers)
+    double* __restrict__ qm = row_qm(k);
+    const double* __restrict__ qin = row_in(k);
+    const double* __restrict__ qlo = row_lo(k);
+    const double* __restrict__ qhi = row_hi(k);
+    const double* __restrict__ qpv = row_pv(k);
+    if (VEC == 2) {
+      const d2* __restrict__ vin = reinterpret_cast<const d2*>(qin);
+      const d2* __restrict__ vlo = reinterpret_cast<const d2*>(qlo);
+      const d2* __restrict__ vhi = reinterpret_cast<const d2*>(qhi);
+      const d2* __restrict__ vpv = reinterpret_cast<const d2*>(qpv);
+      d2* __restrict__ vout = reinterpret_cast<d2*>(qm);
+      for (int i2 = threadIdx.x; i2 < cnt2; i2 += kBlock) {
+        const d2 q = __builtin_nontemporal_load(vin + i2), lo = __builtin_nontemporal_load(vlo + i2),
+          hi = __builtin_nontemporal_load(vhi + i2);
+        d2 cl;
+        cl.x = rmin(hi.x, rmax(lo.x, q.x));
+        cl.y = rmin(hi.y, rmax(lo.y, q.y));
+        vout[i2] = cl;
+        park2(2*i2, cl, qpv ? __builtin_nontemporal_load(vpv + i2) : q, lo, hi);
+      }
+    } else {
+      for (int i = threadIdx.x; i < cnt; i += kBlock) {
+        const double q = __builtin_nontemporal_load(qin + i), lo = __builtin_nontemporal_load(qlo + i),
+          hi = __builtin_nontemporal_load(qhi + i);
+        const double cl = rmin(hi, rmax(lo, q));
+        qm[i] = cl;
+        park1(i, cl, qpv ? __builtin_nontemporal_load(qpv + i) : q, lo, hi);
+      }
+    }
+  };
+
+  static_assert(NP <= 2, "wait_regs ties the registers of at most two passes");
+  Regs cur, nxt;
+  if constexpr (NP > 0) load(k0, cur);
+  stage_tile_meta(st, tile, kidsL, lvlL);
+  for (int i = threadIdx.x; i < tile.nout; i += kBlock) outL[i] = st.outs[tile.outs_off + i];
+  const Micro m = get_micro(st, tile, lane);
+  if constexpr (NP > 0) wait_regs(cur);
+  const int nleaf = tile.nleaf;
+  const double* __restrict__ pq = park + wave*rowlen;
+  double* const vr = v + wave*pitch;
+  for (int k = k0; k < k1; ++k) {
+    if constexpr (NP > 0) {
+      if (k + 1 < k1) load(k + 1, nxt);
+      clip_park(k, cur);
+    } else {
+      clip_park_loop(k);
+    }
+    __syncthreads();
+    // wave 'wave' = quantity: group sums of this lane's micro-subtree, 0 + c0 + c1 + ... (cedr_caas.cpp:147-156,161-165)
+    double leaf[3] = {0, 0, 0};
+#if defined(CEDR_DIAG_BFB_NOTAIL) || defined(CEDR_DIAG_BFB_NOPARK)
+    if (na < 0)
+#endif
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      if (s < m.size) {
+        const int base = (m.start + s)*na;
+        double acc = 0;
+        for (int a = 0; a < na; ++a) { const int i = base + a; acc += pq[i + (i >> sh)]; }
+        leaf[s] = acc;
+      }
+    }
+    if (lane < nleaf) vr[lane] = micro_up_sum_zi(m.shape, leaf[0], leaf[1], leaf[2]);
+#if defined(CEDR_DIAG_BFB_NOTAIL) || defined(CEDR_DIAG_BFB_NOPARK)
+    if (na < 0)
+#endif
+    for (int lv = 0; lv < tile.nlvl; ++lv) {
+      wave_lds_order();
+      const int a = lvlL[lv], b = lvlL[lv+1];
+      for (int j = a + lane; j < b; j += kWave) {
+        const uint32_t kk = kidsL[j];
+        vr[nleaf + j] = (0.0 + vr[kk & 0xffff]) + vr[kk >> 16];
+      }
+    }
+    wave_lds_order();
+    // (the wait for the next tracer's cells comes BEFORE this tracer's output stores are issued: vmcnt counts
+    // stores too, so waiting after them would also wait for their write acknowledgements)
+    // (unconditional, also after the last tracer, when nothing was loaded: tools/check_prefetch_isa.py follows paths,
+    // and a path that skips the wait would reach the copies below with the registers still marked in flight)
+    if constexpr (NP > 0) wait_regs(nxt);
+    double* __restrict__ orow = bd + static_cast<size_t>(wave*nt + k)*stride + tile.out;
+#if defined(CEDR_DIAG_BFB_NOTAIL) || defined(CEDR_DIAG_BFB_NOPARK) || defined(CEDR_DIAG_BFB_NOOUT)
+    if (na < 0)
+#endif
+    for (int o = lane; o < tile.nout; o += kWave) orow[o] = vr[outL[o]];
+    if (k + 1 < k1) __syncthreads();  // the next tracer's cells overwrite the parked ones
+    if constexpr (NP > 0) cur = nxt;
+  }
+}
+
+// A first-stage BFB tile's tables as ONE element per thread, held in registers: fetched together with the first tracer's
+// cells and written to LDS once those cells have arrived. (The tables hang off the tile descriptor; fetched in front
+// of the stream loads, or behind them, they put one more dependent memory round trip into a workgroup's life, and a
+// workgroup that is not streaming is occupancy lost: the launch took 0.45 ms either way.) Inline-asm loads like the
+// cells': hipcc waits for an ordinary load at its first use, and it hoists the first uses of these -- loop invariants
+// -- to the top of the kernel. tie_tile_tables() after the cells' wait marks them arrived.
+struct TileTables { uint32_t kid, mic; int32_t lvl, out; };
+__device__ __forceinline__ void load_tile_tables (const cedr_hip_stage& st, const cedr_hip_tile& tile, TileTables& r) {
+  const int t = threadIdx.x, lane = threadIdx.x & (kWave - 1);
+  const uint32_t* const kp = reinterpret_cast<const uint32_t*>(st.kids + 2*static_cast<size_t>(tile.kids_off));
+  if (t < tile.nint) asm volatile("global_load_dword %0, %1, off" : "=&v"(r.kid) : "v"(kp + t) : "memory");
+  if (t <= tile.nlvl) asm volatile("global_load_dword %0, %1, off" : "=&v"(r.lvl) : "v"(st.lvlptr + tile.lvl_off + t) : "memory");
+  if (t < tile.nout) asm volatile("global_load_ushort %0, %1, off" : "=&v"(r.out) : "v"(st.outs + tile.outs_off + t) : "memory");
+  if (lane < tile.nleaf) asm volatile("global_load_ushort %0, %1, off" : "=&v"(r.mic) : "v"(st.micro + tile.micro_off + lane) : "memory");
+}
+__device__ __forceinline__ void tie_tile_tables (TileTables& r) {
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(r.kid), "+v"(r.mic), "+v"(r.lvl), "+v"(r.out) :: "memory");
+}
+__device__ __forceinline__ void store_tile_tables (const TileTables& r, const cedr_hip_tile& tile, uint32_t* kidsL,
+                                                   int32_t* lvlL, int32_t* outL) {
+  const int t = threadIdx.x;
+  if (t < tile.nint) kidsL[t] = r.kid;
+  if (t <= tile.nlvl) lvlL[t] = r.lvl;
+  if (t < tile.nout) outL[t] = r.out & 0xffff;
+}
+
+// Lane L-1's value within a row of 16 lanes (DPP row_shr:1: a VALU move, no LDS traffic); lanes 0, 16, 32, 48 keep x.
+__device__ __forceinline__ double row_shr1 (const double x) {
+  const int lo = __double2loint(x), hi = __double2hiint(x);
+  return __hiloint2double(__builtin_amdgcn_update_dpp(hi, hi, 0x111, 0xf, 0xf, false),
+                          __builtin_amdgcn_update_dpp(lo, lo, 0x111, 0xf, 0xf, false));
+}
+
+// The same fusion for groups of na = 2, 4, 8, 16 or 32 cells (16-byte accesses): the group sums are formed IN REGISTERS.
+// Thread i2 of a tile holds the cell pair (2 i2, 2 i2 + 1); a group is g = na/2 consecutive lanes, never split
+// over two DPP rows (16 % g == 0, tiles start on a group boundary). The reference's sequential sum
+// 0 + c0 + c1 + ... (cedr_caas.cpp:147-156) runs along the lanes of a group: lane j takes lane j-1's partial sum
+// (row_shr:1) and adds its own two cells, g - 1 steps; the group's last lane holds the result and writes it to LDS.
+// Only the leaf values (4 quantities x <= 192 leaves) touch LDS, double-buffered so that one barrier per tracer is
+// enough, and nothing is parked: ~10 KB of LDS and ~50 VGPRs per workgroup instead of 35 KB and 112, i.e. the
+// occupancy of caas_reduce_kernel, whose streaming rate this kernel is built to keep (at 4 workgroups per CU
+// that kernel itself drops from 0.383 to 0.423 ms, at 3 to 0.50: profiles/r05_experiments.md).
+template <int NP>
+__global__ __launch_bounds__(kBlock)
+void caas_reduce_bfb_p2_kernel (const int32_t* __restrict__ probs, const int nt, const int n,
+                                const int need_conserve, const int lg,
+                                double* __restrict__ d, const double* __restrict__ qm_src,
+                                const cedr_hip_stage st, const int32_t* __restrict__ tile_nl,
+                                const int64_t stride, double* __restrict__ bd, const int leafpitch,
+                                const int pitch, const int tper) {
+  static_assert(NP == 1 || NP == 2, "wait_regs ties the registers of one or two passes");
+  extern __shared__ double lds[];
+  const int tix = xcd_tile(st.ntiles);
+  if (tix < 0) return;
+  const int k0 = blockIdx.y*tper, k1 = min(nt, k0 + tper);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & (kWave - 1);
+#ifdef CEDR_DIAG_P2_NODESC  // (diagnostic builds, wrong results: no descriptor fetch in front of the stream loads)
+  const cedr_hip_tile tile = {0, 64, 0, 48, 0, 0, 2, 0, 16, 0};
+  const int nl = 128;
+#else
+  const cedr_hip_tile tile = st.tiles[tix];
+  const int nl = tile_nl[tix];
+#endif
+  uint32_t* const kidsL = reinterpret_cast<uint32_t*>(lds);
+  int32_t* const lvlL = reinterpret_cast<int32_t*>(kidsL + st.max_nint);
+  int32_t* const outL = reinterpret_cast<int32_t*>(lds + (st.max_nint + 1));
+  double* const v = lds + (st.max_nint + 1) + kWave/2;
+  double* const leafL = v + static_cast<size_t>(kNW)*pitch;  // [2][4][leafpitch]
+  const size_t N = n;
+  const int g = 1 << lg, j = lane & (g - 1);
+#ifdef CEDR_DIAG_BFB_GEOM  // (diagnostic builds, wrong results)
+  const int64_t cell0 = static_cast<int64_t>(tix)*CEDR_DIAG_BFB_GEOM;
+  const int cnt2 = CEDR_DIAG_BFB_GEOM/2 + 0*nl;
+#else
+  const int64_t cell0 = static_cast<int64_t>(tile.in0) << (lg + 1);
+  const int cnt2 = nl << lg;  // cell pairs of the tile
+#endif
+  typedef double __attribute__((ext_vector_type(2))) d2;
+  const int nleaf = tile.nleaf;
+  double* const vr = v + wave*pitch;
+  struct Regs { d2 q[NP], lo[NP], hi[NP], pv[NP]; };
+  // The cells of tracer k: inline-asm loads (see caas_reduce_bfb_kernel), UNCONDITIONAL -- threads past the tile's last
+  // pair re-read it -- so that both passes' loads are issued back to back (with ordinary loads under a per-pass branch
+  // the compiler waited for the first pass before it asked for the second). A tracer without Qm_prev re-reads its Qm
+  // row for the second sum (cache hits).
+  auto load = [&] (const int k, const int b0, Regs& r) {
+    const d2* const vin = reinterpret_cast<const d2*>((qm_src ? qm_src + k*N : d + (1 + k)*N) + cell0);
+    const d2* const vlo = reinterpret_cast<const d2*>(d + (1 + nt + k)*N + cell0);
+    const d2* const vhi = reinterpret_cast<const d2*>(d + (1 + 2*static_cast<size_t>(nt) + k)*N + cell0);
+    const d2* const vpv = (need_conserve && (probs[k] & CONSERVE) != 0) ?
+      reinterpret_cast<const d2*>(d + (1 + 3*static_cast<size_t>(nt) + k)*N + cell0) : vin;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int i2 = min(b0 + static_cast<int>(threadIdx.x) + kBlock*p, cnt2 - 1);
+      asm volatile("global_load_dwordx4 %0, %1, off nt" : "=&v"(r.q[p]) : "v"(vin + i2) : "memory");
+      asm volatile("global_load_dwordx4 %0, %1, off nt" : "=&v"(r.lo[p]) : "v"(vlo + i2) : "memory");
+      asm volatile("global_load_dwordx4 %0, %1, off nt" : "=&v"(r.hi[p]) : "v"(vhi + i2) : "memory");
+      asm volatile("global_load_dwordx4 %0, %1, off nt" : "=&v"(r.pv[p]) : "v"(vpv + i2) : "memory");
+    }
+  };
+  auto wait_regs = [&] (Regs& r) {
+    if constexpr (NP == 1)
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(r.q[0]), "+v"(r.lo[0]), "+v"(r.hi[0]), "+v"(r.pv[0]) :: "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(r.q[0]), "+v"(r.lo[0]), "+v"(r.hi[0]), "+v"(r.pv[0]),
+                   "+v"(r.q[NP-1]), "+v"(r.lo[NP-1]), "+v"(r.hi[NP-1]), "+v"(r.pv[NP-1]) :: "memory");
+  };
+  // one pass: the pair i2 of tracer k -- clip, write back, the running sums of its group along the lanes
+  auto pass = [&] (const int i2, const d2 q, const d2 lo, const d2 hi, const d2 term, d2* __restrict__ vout,
+                   double* __restrict__ lf) {
+    d2 cl;
+    cl.x = rmin(hi.x, rmax(lo.x, q.x));
+    cl.y = rmin(hi.y, rmax(lo.y, q.y));
+    vout[i2] = cl;
+    double s0 = (0.0 + cl.x) + cl.y, s1 = (0.0 + term.x) + term.y, s2 = (0.0 + lo.x) + lo.y, s3 = (0.0 + hi.x) + hi.y;
+    for (int step = 1; step < g; ++step) {
+      const double t0 = row_shr1(s0), t1 = row_shr1(s1), t2 = row_shr1(s2), t3 = row_shr1(s3);
+      if (j == step) {
+        s0 = (t0 + cl.x) + cl.y; s1 = (t1 + term.x) + term.y; s2 = (t2 + lo.x) + lo.y; s3 = (t3 + hi.x) + hi.y;
+      }
+    }
+    if (j == g - 1) {
+      const int leaf = i2 >> lg;
+      lf[leaf] = s0; lf[leafpitch + leaf] = s1; lf[2*leafpitch + leaf] = s2; lf[3*leafpitch + leaf] = s3;
+    }
+  };
+  TileTables tt{0u, 0u, 0, 0};
+  Regs r;
+  load_tile_tables(st, tile, tt);
+  load(k0, 0, r);
+  wait_regs(r);
+  tie_tile_tables(tt);
+  store_tile_tables(tt, tile, kidsL, lvlL, outL);
+  const Micro m = decode_micro(tt.mic, lane < nleaf);
+  for (int k = k0; k < k1; ++k) {
+    d2* __restrict__ vout = reinterpret_cast<d2*>(d + (1 + k)*N + cell0);
+    double* __restrict__ lf = leafL + static_cast<size_t>((k - k0) & 1)*4*leafpitch;
+    // (a tile of more than NP*512 cells -- groups of 8 cells and more -- takes several rounds of NP passes)
+    for (int b0 = 0; b0 < cnt2; b0 += NP*kBlock) {
+      if (k != k0 || b0 != 0) { load(k, b0, r); wait_regs(r); }
+      // (whole groups are active or not: cnt2 is a multiple of g, and so is every pass's first pair)
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        const int i2 = b0 + threadIdx.x + kBlock*p;
+        if (i2 < cnt2) pass(i2, r.q[p], r.lo[p], r.hi[p], r.pv[p], vout, lf);
+      }
+    }
+    __syncthreads();  // (the leaf values; before the first tracer also the tile's tables)
+#ifdef CEDR_DIAG_P2_NOTAIL
+    if (lg >= 0) continue;
+#endif
+    // wave 'wave' = quantity: this lane's micro-subtree, then the tile's LDS levels, 0 + kid0 + kid1
+    const double* __restrict__ lq = lf + wave*leafpitch + m.start;
+    if (lane < nleaf) vr[lane] = micro_up_sum_zi(m.shape, lq[0], lq[1], lq[2]);
+    for (int lv = 0; lv < tile.nlvl; ++lv) {
+      wave_lds_order();
+      const int a = lvlL[lv], b = lvlL[lv+1];
+      for (int jn = a + lane; jn < b; jn += kWave) {
+        const uint32_t kk = kidsL[jn];
+        vr[nleaf + jn] = (0.0 + vr[kk & 0xffff]) + vr[kk >> 16];
+      }
+    }
+    wave_lds_order();
+    double* __restrict__ orow = bd + static_cast<size_t>(wave*nt + k)*stride + tile.out;
+    for (int o = lane; o < tile.nout; o += kWave) orow[o] = vr[outL[o]];
+    wave_lds_order();  // this wave's next micro roots overwrite vr
   }
 }
 
@@ -2645,13 +3029,13 @@ __global__ void node_problem_batch_kernel (const int pt, const int nprob, const 
 // is launched on. Off by default; bench.py switches it on for its roofline leg.
 enum KernelId : int { K_TREE_UP = 0, K_QLT_DOWN, K_QLT_ROOT, K_GATHER, K_SCATTER, K_COPY,
                       K_SET_RHOM, K_SET_QM, K_GET_QM, K_CAAS_REDUCE, K_CAAS_SUM, K_CAAS_ACCUM,
-                      K_CAAS_FINISH, K_APEX, K_LEVEL, K_TOP_UP, K_QLT_TOP, K_COUNT };
+                      K_CAAS_FINISH, K_APEX, K_LEVEL, K_TOP_UP, K_QLT_TOP, K_CAAS_BFB, K_COUNT };
 const char* const kKernelNames[K_COUNT] = {
   "tree_up_kernel", "qlt_down_kernel", "qlt_root_kernel", "gather_slots_kernel",
   "scatter_slots_kernel", "copy_slots_kernel", "qlt_set_rhom_kernel", "qlt_set_Qm_kernel",
   "qlt_get_Qm_kernel", "caas_reduce_kernel", "caas_sum_partials_kernel",
   "caas_reduce_accum_kernel", "caas_finish_kernel", "apex_kernel", "level_kernel", "tree_top_up_kernel",
-  "qlt_top_kernel" };
+  "qlt_top_kernel", "caas_reduce_bfb_kernel" };
 
 struct ProfRec { int id; int64_t aux; hipEvent_t a, b; };
 struct Profiler {
@@ -3137,11 +3521,13 @@ int cedr_hip_caas_reduce_local_arrays (const int32_t* probs, int32_t nt, int32_t
                         static_cast<const void*>(qm_min), static_cast<const void*>(qm_max),
                         static_cast<const void*>(qm_prev)})
     if (p && reinterpret_cast<uintptr_t>(p) % 16) vec = false;
+  // (experiments: CEDR_HIP_CAAS_LDS_PAD bytes of unused LDS per workgroup lower the occupancy)
+  static const size_t lds_pad = [] { const char* v = std::getenv("CEDR_HIP_CAAS_LDS_PAD"); return v ? static_cast<size_t>(std::atol(v)) : 0; }();
   if (vec)
-    hipLaunchKernelGGL(caas_reduce_kernel<2>, grid, dim3(kBlock), 0, stream, probs, nt, n,
+    hipLaunchKernelGGL(caas_reduce_kernel<2>, grid, dim3(kBlock), lds_pad, stream, probs, nt, n,
                        need_conserve, qm_in, qm_out, qm_min, qm_max, qm_prev, partials);
   else
-    hipLaunchKernelGGL(caas_reduce_kernel<1>, grid, dim3(kBlock), 0, stream, probs, nt, n,
+    hipLaunchKernelGGL(caas_reduce_kernel<1>, grid, dim3(kBlock), lds_pad, stream, probs, nt, n,
                        need_conserve, qm_in, qm_out, qm_min, qm_max, qm_prev, partials);
   return launch_status();
 }
@@ -3189,6 +3575,98 @@ int cedr_hip_caas_reduce_local_accum (const int32_t* probs, int32_t nt, int32_t 
   const int total = 2*nt*(n/na);
   hipLaunchKernelGGL(caas_reduce_accum_kernel, dim3((total + kBlock - 1)/kBlock), dim3(kBlock), 0,
                      stream, probs, nt, n, need_conserve, na, d, qm_src, send);
+  return launch_status();
+}
+
+// LDS bytes caas_reduce_bfb_kernel needs for tiles of at most max_tile_leaves leaves of n_accum cells; the skew shift.
+static inline int bfb_skew_shift (const int na) { int sh = 0; while ((2 << sh) <= na) ++sh; return sh; }
+static inline size_t bfb_fused_lds (const cedr_hip_stage* st, const int na, const int max_tile_leaves, int* rowlen,
+                                    int* pitch) {
+  const int64_t cells = static_cast<int64_t>(max_tile_leaves)*na;
+  *rowlen = static_cast<int>(cells + (cells >> bfb_skew_shift(na))) + 1;
+  *pitch = pitch_for(st->max_nodes);
+  return sizeof(double)*(meta_doubles(st) + kWave/2 + static_cast<size_t>(kNW)*(*pitch) + 4*static_cast<size_t>(*rowlen));
+}
+// Groups of 2, 4, 8, 16 or 32 cells take the kernel that sums them in registers (caas_reduce_bfb_p2_kernel; its
+// 16-byte accesses need 16-byte aligned rows, which the caller checks); lg = log2(lanes per group).
+static inline bool bfb_p2_group (const int na, int* lg) {
+  for (int e = 0; e <= 4; ++e) if (na == (2 << e)) { *lg = e; return true; }
+  return false;
+}
+
+int cedr_hip_caas_bfb_fusable (const cedr_hip_stage* st, int32_t n_accum, int32_t max_tile_leaves, int aligned16,
+                               int flags) {
+  static_assert(kNW == 4, "one wave per quantity {clip, term, min, max}");
+  if ( ! st || ! st->micro || st->ntiles < 1 || st->max_nleaf > kWave || n_accum < 1 || max_tile_leaves < 1 ||
+      max_tile_leaves > 3*kWave || static_cast<int64_t>(max_tile_leaves)*n_accum > 8192)
+    return 0;
+  int rowlen, pitch, lg;
+  if (aligned16 && bfb_p2_group(n_accum, &lg) && ! (flags & CEDR_CAAS_BFB_PARK)) return 1;
+  return bfb_fused_lds(st, n_accum, max_tile_leaves, &rowlen, &pitch) <= kBfbFusedMaxLds ? 1 : 0;
+}
+
+int cedr_hip_caas_reduce_local_bfb (const int32_t* probs, int32_t nt, int32_t n, int need_conserve,
+                                    int32_t na, double* d, const double* qm_src,
+                                    const cedr_hip_stage* st, const int32_t* tile_nleaves,
+                                    int32_t max_tile_leaves, int64_t stride, double* bd, int flags,
+                                    cedr_stream_t stream) {
+  ProfScope ps(K_CAAS_BFB, n, stream);
+  // 16-byte accesses when every row and every tile's first cell sit on a 16-byte boundary
+  const bool vec = n % 2 == 0 && na % 2 == 0 && reinterpret_cast<uintptr_t>(d) % 16 == 0 &&
+    ( ! qm_src || reinterpret_cast<uintptr_t>(qm_src) % 16 == 0);
+  if ( ! cedr_hip_caas_bfb_fusable(st, na, max_tile_leaves, vec, flags) || n % na || nt < 1)
+    return static_cast<int>(hipErrorInvalidValue);
+  int rowlen, pitch;
+  const size_t lds = bfb_fused_lds(st, na, max_tile_leaves, &rowlen, &pitch);
+  const int sh = bfb_skew_shift(na);
+#ifdef CEDR_DIAG_BFB_GEOM
+  const int maxcells = CEDR_DIAG_BFB_GEOM;
+#else
+  const int maxcells = max_tile_leaves*na;
+#endif
+  int lg = 0;
+  bool p2 = vec && bfb_p2_group(na, &lg) && ! (flags & CEDR_CAAS_BFB_PARK);
+  if ( ! p2 && lds > kBfbFusedMaxLds) return static_cast<int>(hipErrorInvalidValue);
+  // Tracers per workgroup: enough workgroups for several rounds, and otherwise as many tracers as possible
+  // behind one descriptor fetch (CEDR_HIP_CAAS_BFB_WGS: workgroups wanted).
+  static const int wgs_env = [] { const char* v = std::getenv("CEDR_HIP_CAAS_BFB_WGS"); return v ? std::atoi(v) : 0; }();
+  const int wgs_wanted = wgs_env > 0 ? wgs_env : (p2 ? kBfbFusedWgsP2 : kBfbFusedWgs);
+  int ysplit = (wgs_wanted + st->ntiles - 1)/st->ntiles;
+  if (ysplit > nt) ysplit = nt;
+  if (ysplit < 1) ysplit = 1;
+  const int tper = (nt + ysplit - 1)/ysplit;
+#ifdef CEDR_DIAG_BFB_GEOM
+  cedr_hip_stage stg = *st;
+  stg.ntiles = std::min(st->ntiles, n/(CEDR_DIAG_BFB_GEOM));
+  st = &stg;
+#endif
+  const dim3 grid(xcd_grid(st->ntiles), (nt + tper - 1)/tper);
+  if (p2) {
+    const int leafpitch = (max_tile_leaves + 3) | 1;
+    const size_t ldsp = sizeof(double)*(meta_doubles(st) + kWave/2 + static_cast<size_t>(kNW)*pitch + 8*static_cast<size_t>(leafpitch));
+    auto gop = [&] (auto kernel) -> int {
+      const int e = set_lds_limit(kernel, ldsp);
+      if (e) return e;
+      hipLaunchKernelGGL(kernel, grid, dim3(kBlock), ldsp, stream, probs, nt, n, need_conserve, lg, d, qm_src,
+                         *st, tile_nleaves, stride, bd, leafpitch, pitch, tper);
+      return 0;
+    };
+    const int e = maxcells <= 2*kBlock ? gop(caas_reduce_bfb_p2_kernel<1>) : gop(caas_reduce_bfb_p2_kernel<2>);
+    if (e) return e;
+    return launch_status();
+  }
+  auto go = [&] (auto kernel) -> int {
+    const int e = set_lds_limit(kernel, lds);
+    if (e) return e;
+    hipLaunchKernelGGL(kernel, grid, dim3(kBlock), lds, stream, probs, nt, n, need_conserve, na, sh, d, qm_src,
+                       *st, tile_nleaves, stride, bd, rowlen, pitch, tper);
+    return 0;
+  };
+  int e;
+  if (vec) e = maxcells <= 2*kBlock ? go(caas_reduce_bfb_kernel<2, 1>) :
+         (maxcells <= 4*kBlock ? go(caas_reduce_bfb_kernel<2, 2>) : go(caas_reduce_bfb_kernel<2, 0>));
+  else e = go(caas_reduce_bfb_kernel<1, 0>);
+  if (e) return e;
   return launch_status();
 }
 
@@ -3277,6 +3755,11 @@ int cedr_hip_debug_stamps (unsigned long long* out, int reset) {
   return e;
 }
 #endif
+
+#ifndef CEDR_KERNELS_SHA
+# define CEDR_KERNELS_SHA "unknown"
+#endif
+const char* cedr_hip_kernels_sha256 (void) { return CEDR_KERNELS_SHA; }
 
 const char* cedr_hip_profile_name (int id) {
   return (id >= 0 && id < K_COUNT) ? kKernelNames[id] : "";

@@ -222,6 +222,25 @@ int cedr_hip_caas_sum_partials(int32_t nt, int32_t n, const double* partials, do
 int cedr_hip_caas_reduce_local_accum(const int32_t* probs, int32_t nt, int32_t n,
                                      int need_conserve, int32_t n_accum, double* d,
                                      const double* qm_src, double* send, cedr_stream_t stream);
+/* The production pairing, fused: CAAS whose UserAllReducer is the library's own BFB tree reducer over groups
+ * of n_accum cells. The user-reducer reduce pass (cedr_caas.cpp:137-168) AND the leaf fill + first
+ * leaves->root stage of BfbTreeAllReducer::allreduce (cedr_bfb_tree_allreduce.cpp:91-124) in one launch:
+ * the group sums never reach HBM; the tile outputs of `bfb_stage` (the reducer's first local stage: micro
+ * tiles whose leaf i is the cell group i, fields in CAAS's send order q*nt + tracer, q = clip, term, min,
+ * max) are written to bfb_data[field*bfb_stride + slot]. tile_nleaves[t] = leaves under tile t (device
+ * array); max_tile_leaves their maximum. The tiles must cover the n/n_accum local leaves exactly once.
+ * cedr_hip_caas_bfb_fusable: 1 if such a stage / group size can be launched. Groups of 2, 4, 8, 16 or 32 cells on
+ * 16-byte aligned rows (aligned16: n even, d and qm_src 16-byte aligned) are summed in registers; any other
+ * group size parks a tile's cells in LDS (32 B per cell: up to ~2000 cells per tile); flags: CEDR_CAAS_BFB_PARK
+ * takes the LDS form for every group size (tests). */
+enum { CEDR_CAAS_BFB_PARK = 1 };
+int cedr_hip_caas_bfb_fusable(const cedr_hip_stage* bfb_stage, int32_t n_accum, int32_t max_tile_leaves,
+                              int aligned16, int flags);
+int cedr_hip_caas_reduce_local_bfb(const int32_t* probs, int32_t nt, int32_t n, int need_conserve,
+                                   int32_t n_accum, double* d, const double* qm_src,
+                                   const cedr_hip_stage* bfb_stage, const int32_t* tile_nleaves,
+                                   int32_t max_tile_leaves, int64_t bfb_stride, double* bfb_data, int flags,
+                                   cedr_stream_t stream);
 /* CAAS::finish_locally (cedr_caas.cpp:211-253). recv[4*nt]. */
 int cedr_hip_caas_finish_local(int32_t nt, int32_t n, double* d, const double* recv,
                                cedr_stream_t stream);
@@ -239,6 +258,9 @@ void cedr_hip_profile_start(void);
 int cedr_hip_profile_stop(void);
 int cedr_hip_profile_get(int i, int* id, int64_t* aux, float* ms);
 const char* cedr_hip_profile_name(int id);
+/* sha256 (hex) of the kernel source file this library was built from (compose_amd/csrc/cedr_kernels.hip):
+ * stamped into benchmark lines and profiles so that a measurement can be matched to its code. */
+const char* cedr_hip_kernels_sha256(void);
 
 /* ------------------------------------------------------------------ layer O */
 /* Handles are opaque. Creation functions return NULL on failure. */
@@ -394,6 +416,15 @@ typedef int (*cedr_user_allreduce_fn)(void* user, double* sendbuf, double* rcvbu
                                       int nfld);
 void* cedr_caas_create(void* parallel, int nlclcells, cedr_user_allreduce_fn reducer,
                        int n_accum_in_place, void* user);
+/* The production pairing: CAAS whose UserAllReducer is the library's own BFB tree reducer `bfb` (a
+ * cedr_bfb_create handle over a tree whose leaf i is the group of cells [i*n_accum, (i+1)*n_accum) of this
+ * rank, nfield = 4 * #tracers; it stays the caller's to free, the CAAS shares it): C++ callers pass a
+ * caas::BfbUserAllReducer. run() then fuses the reduce pass with the reducer's first tree stage
+ * (cedr_hip_caas_reduce_local_bfb) where the tree allows it -- cedr_caas_fused_with_bfb says, after
+ * finish_setup -- and otherwise runs the two one after the other; the results are bit-identical either way
+ * and to a cedr_caas_create whose callback calls cedr_bfb_allreduce(bfb, send, recv, 1). */
+void* cedr_caas_create_bfb(void* parallel, int nlclcells, void* bfb, int n_accum_in_place);
+int cedr_caas_fused_with_bfb(void* caas);
 void cedr_caas_free(void* caas);
 int cedr_caas_declare_tracer(void* caas, int problem_type, int rhomidx);
 int cedr_caas_end_tracer_declarations(void* caas);

@@ -115,3 +115,69 @@ def caas_exact_sums(v, tracers):
                 x = np.minimum(hi, clip + (m / fac) * (hi - clip))
         out[k] = x
     return out
+
+
+def caas_bfb_expected(oracle, v, types, ngroups, accum, imbalanced=False):
+    """CAAS paired with the BFB tree reducer over groups of `accum` cells, restated from the reference with the
+    ORACLE's tree sum in the middle: clip and per-group partial sums 0 + c0 + c1 + ... (cedr_caas.cpp:140-168),
+    oracle.bfb_allreduce over the transposed (field, group) layout (cedr_bfb_tree_allreduce.cpp:79-159),
+    adjust_Qm (cedr_caas.cpp:217-252). numpy evaluates every step in IEEE double without fusing, so the HIP
+    result must equal this bit for bit."""
+    nt, n = v.Qm.shape
+    assert n == ngroups * accum
+    clip = np.where(v.Qm_max < np.where(v.Qm_min > v.Qm, v.Qm_min, v.Qm), v.Qm_max,
+                    np.where(v.Qm_min > v.Qm, v.Qm_min, v.Qm))
+    cons = np.array([(t & 1) != 0 for t in types])
+    term = np.where(cons[:, None], v.Qm_prev, v.Qm)
+    send = np.zeros((4 * nt, ngroups))
+    for q, arr in enumerate((clip, term, v.Qm_min, v.Qm_max)):
+        a3 = arr.reshape(nt, ngroups, accum)
+        acc = np.zeros((nt, ngroups))
+        for ai in range(accum):
+            acc = acc + a3[:, :, ai]
+        send[q * nt:(q + 1) * nt] = acc
+    recv = oracle.bfb_allreduce(oracle.Tree.make_1d(ngroups, 1, False, imbalanced), ngroups, 1, 4 * nt, True,
+                                [send])[0]
+    out = clip.copy()
+    for k in range(nt):
+        m = recv[nt + k] - recv[k]
+        if m < 0:
+            fac = recv[k] - recv[2 * nt + k]
+            if fac > 0:
+                fac = m / fac
+                x = out[k] + fac * (out[k] - v.Qm_min[k])
+                out[k] = np.where(v.Qm_min[k] > x, v.Qm_min[k], x)
+        elif m > 0:
+            fac = recv[3 * nt + k] - recv[k]
+            if fac > 0:
+                fac = m / fac
+                x = out[k] + fac * (v.Qm_max[k] - out[k])
+                out[k] = np.where(v.Qm_max[k] < x, v.Qm_max[k], x)
+    return out
+
+
+def run_hip_caas_bfb(ca, ngroups, accum, types, v, typed, imbalanced=False, qm_source=False, nrepeat=1):
+    """CAAS + BfbTreeAllReducer on one rank. typed: the reducer object itself is CAAS's UserAllReducer
+    (caas::BfbUserAllReducer: run() may fuse); else a callback that calls allreduce (never fused).
+    Returns (masses, fused?)."""
+    p = ca.Parallel.self_()
+    ncells = ngroups * accum
+    nt = len(types)
+    bfb = ca.BfbTreeAllReducer(p, ca.Tree.make_1d(ngroups, 1, False, imbalanced), ngroups, 4 * nt)
+    red = bfb if typed else (lambda s, r, nl, nf: bfb.allreduce(s, r, True))
+    c = ca.CAAS(p, ncells, red, accum)
+    for t in types:
+        c.declare_tracer(t, 0)
+    c.end_tracer_declarations()
+    c.finish_setup()
+    d = [ca.DeviceArray.from_numpy(a) for a in (v.rhom, v.Qm, v.Qm_min, v.Qm_max, v.Qm_prev)]
+    c.set_rhom(d[0])
+    for _ in range(nrepeat):
+        c.set_Qm(d[1], d[2], d[3], d[4])
+        if qm_source:
+            c.set_Qm_source(d[1])
+        c.run()
+    out_d = ca.DeviceArray(v.Qm.size)
+    c.get_Qm(out_d)
+    ca.synchronize()
+    return out_d.numpy(v.Qm.shape), c.fused_with_bfb()

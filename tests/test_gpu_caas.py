@@ -64,6 +64,59 @@ def test_caas_user_reducer(gpu, oracle, ncells, accum):
     assert np.array_equal(got, want)  # same summation order as the oracle => bit for bit
 
 
+# The production pairing: CAAS + the library's BFB tree reducer. (groups, cells per group): tiles of 183-192 leaves;
+# accum 4 = the profile's case; 2, 4, 8, 16, 32: group sums in registers along the lanes (park: the LDS form instead,
+# where a tile's cells fit); 3 and 1: odd groups (8-byte loads, LDS form); 6, 10: LDS form, 10 with more than 1024 cells
+# per tile (loop form); 44, 64: too many cells for a tile's LDS -> not fused; 1500 groups: one stage of micro tiles
+# under the top tile; 40 groups: a single tile.
+@pytest.mark.parametrize("ngroups,accum,expect_fused", [
+    (5000, 4, True), (5000, 3, True), (3000, 1, True), (4097, 2, True), (2500, 10, True), (40000, 4, True),
+    (2304, 44, False), (1500, 4, True), (40, 4, None), (12345, 6, True), (3000, 16, True), (2001, 8, True),
+    (1500, 32, True), (700, 64, False)])
+@pytest.mark.parametrize("imbalanced", [False, True])
+@pytest.mark.parametrize("park", [False, True])
+def test_caas_bfb_pairing_fused_bitwise(gpu, oracle, monkeypatch, ngroups, accum, expect_fused, imbalanced, park):
+    """CAAS whose UserAllReducer is the BFB tree reducer (cedr_caas.cpp:137-168,263-266 +
+    cedr_bfb_tree_allreduce.cpp:79-159): the fused kernel (typed pairing) gives the bits of the two separate
+    launches (callback pairing) and of the restatement with the oracle's tree sum."""
+    ca = gpu
+    if park:  # the LDS form of the fused kernel also for the group sizes that are otherwise summed in registers
+        if accum not in (2, 4, 8, 16, 32):
+            pytest.skip("no register form for this group size anyway")
+        monkeypatch.setenv("CEDR_HIP_CAAS_BFB_P2", "0")
+        if accum >= 16:
+            expect_fused = None  # (too many cells per tile for the LDS form, unless the tree's tiles are small)
+    trs = R.caas_tracers(R.tracers_vector())
+    types = [t.problem_type for t in trs]
+    v = R.make_values(trs, ngroups * accum, seed=ngroups + accum)
+    want = common.caas_bfb_expected(oracle, v, types, ngroups, accum, imbalanced)
+    cb, f0 = common.run_hip_caas_bfb(ca, ngroups, accum, types, v, typed=False, imbalanced=imbalanced)
+    assert not f0
+    assert np.array_equal(cb, want)
+    got, fused = common.run_hip_caas_bfb(ca, ngroups, accum, types, v, typed=True, imbalanced=imbalanced)
+    assert expect_fused is None or fused == expect_fused
+    assert np.array_equal(got, want)
+    nerr, msgs = R.check(trs, v, got)
+    assert nerr == 0, msgs[:5]
+
+
+def test_caas_bfb_pairing_fuse_knob_and_reruns(gpu, oracle, monkeypatch):
+    """CEDR_HIP_CAAS_BFB_FUSE=0 keeps the two launches; repeated run() calls on re-packed inputs and the
+    set_Qm_source form give the same bits."""
+    ca = gpu
+    trs = R.caas_tracers(R.tracers_vector())
+    types = [t.problem_type for t in trs]
+    ngroups, accum = 6000, 4
+    v = R.make_values(trs, ngroups * accum, seed=11)
+    want = common.caas_bfb_expected(oracle, v, types, ngroups, accum)
+    for kw in (dict(nrepeat=3), dict(qm_source=True)):
+        got, fused = common.run_hip_caas_bfb(ca, ngroups, accum, types, v, typed=True, **kw)
+        assert fused and np.array_equal(got, want)
+    monkeypatch.setenv("CEDR_HIP_CAAS_BFB_FUSE", "0")
+    got, fused = common.run_hip_caas_bfb(ca, ngroups, accum, types, v, typed=True)
+    assert not fused and np.array_equal(got, want)
+
+
 def test_caas_qm_source_matches_in_place(gpu):
     ca = gpu
     trs = [R.Tracer(i, 7, 1) for i in range(5)]

@@ -179,8 +179,8 @@ def test_config_C_sharded_8_ways(gpu, oracle):
     threads on this one GPU (tests/threaded_ranks.py: the real gather / all-gather / scatter /
     replicated-top path and the CAAS all-reduce, host-staged transport).
     QLT: bit-identical to the single-rank run; three tracers bit-identical to the oracle.
-    CAAS with the BFB tree all-reduce as its UserAllReducer (the production pairing): bit-identical on
-    1 and 8 ranks. CAAS with its own all-reduce: per tracer within 1e-13 of the single-rank run and of
+    CAAS with the BFB tree all-reduce as its UserAllReducer (the production pairing), fused (the reducer object is
+    the UserAllReducer) and as two launches (a callback): bit-identical to each other and on 1 and 8 ranks. CAAS with its own all-reduce: per tracer within 1e-13 of the single-rank run and of
     the oracle (8 partial sums are added in another order than one rank's)."""
     import os
     import sys
@@ -205,7 +205,7 @@ def test_config_C_sharded_8_ways(gpu, oracle):
     def run_all(nranks, partial=False):
         """(QLT, CAAS own all-reduce, CAAS + BFB reducer) results as global [nt][n] tensors.
         partial: QLT only, every rank from its own partial tree (tree::Node::level -> level mode)."""
-        outs = [torch.zeros_like(Qm) for _ in range(3)]
+        outs = [torch.zeros_like(Qm) for _ in range(4)]
 
         def body(rank, comm):
             par = comm.parallel(ca, rank)
@@ -235,18 +235,29 @@ def test_config_C_sharded_8_ways(gpu, oracle):
             btree = ca.Tree.make_1d(n // acc, nranks, False, False)
             bfb = ca.BfbTreeAllReducer(par, btree, n // acc, 4 * nt)
             assert bfb.nlocal() == len(g) // acc
-            cb = declare(ca.CAAS(par, len(g), lambda s, r, nl, nf: bfb.allreduce(s, r, True), acc))
+            # the reducer object itself as the UserAllReducer (caas::BfbUserAllReducer): run() fuses the reduce pass
+            # with the first stage of the reducer's tree
+            cb = declare(ca.CAAS(par, len(g), bfb, acc))
+            assert cb.fused_with_bfb()
             cb.set_rhom(loc[0]); cb.set_Qm(loc[1], loc[2], loc[3], loc[4]); cb.run()
             cb.get_Qm(o); ca.synchronize()
             outs[2][:, g] = o
+            del cb
+            # ... and through a callback: the two separate launches
+            cb = declare(ca.CAAS(par, len(g), lambda s, r, nl, nf: bfb.allreduce(s, r, True), acc))
+            assert not cb.fused_with_bfb()
+            cb.set_rhom(loc[0]); cb.set_Qm(loc[1], loc[2], loc[3], loc[4]); cb.run()
+            cb.get_Qm(o); ca.synchronize()
+            outs[3][:, g] = o
             return int(g.numel())
         counts = T.run_ranks(nranks, body, timeout=1200)
         assert counts == [n // nranks] * nranks
         torch.cuda.synchronize()
         return outs
 
-    q1, c1, b1 = run_all(1)
-    q8, c8, b8 = run_all(P)
+    q1, c1, b1, u1 = run_all(1)
+    q8, c8, b8, u8 = run_all(P)
+    assert torch.equal(b1, u1) and torch.equal(b8, u8), "the fused CAAS + BFB path differs from the separate launches"
     assert torch.equal(q1, q8), "QLT depends on the rank count"
     assert torch.equal(q1, run_all(P, partial=True)[0]), "QLT from partial trees (level mode) differs"
     assert torch.equal(b1, b8), "CAAS + BFB reducer depends on the rank count"

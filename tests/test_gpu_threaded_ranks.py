@@ -78,13 +78,16 @@ def test_qlt_bound_arrays_ranks_as_threads(gpu, oracle, nranks, ncells, partial)
     assert np.array_equal(out, want)
 
 
-@pytest.mark.parametrize("accum", [1, 4])
-def test_caas_with_bfb_user_reducer_is_decomposition_invariant(gpu, oracle, accum):
+@pytest.mark.parametrize("typed", [False, True])
+@pytest.mark.parametrize("accum,ngroups", [(1, 96), (4, 96), (4, 24000), (3, 20011)])
+def test_caas_with_bfb_user_reducer_is_decomposition_invariant(gpu, oracle, accum, ngroups, typed):
     """The production pairing (north star): CAAS whose UserAllReducer is the BFB tree
     all-reduce over element partials. The limited masses must be bit-identical on 1, 2, 4
     and 8 ranks -- that is the point of the BFB reducer -- and agree with the oracle's CAAS."""
     ca = gpu
-    ngroups = 96                      # leaves of the reducer's tree ("elements")
+    # ngroups: leaves of the reducer's tree ("elements"); typed: the reducer object itself is the UserAllReducer
+    # (caas::BfbUserAllReducer), which fuses CAAS's reduce pass with the tree's first stage on ranks whose part of
+    # the tree has one (the large cases) -- and must not change a bit
     ncells = ngroups * accum          # cells per element = n_accum_in_place
     trs = R.caas_tracers(R.tracers_vector())
     types = [t.problem_type for t in trs]
@@ -106,11 +109,15 @@ def test_caas_with_bfb_user_reducer_is_decomposition_invariant(gpu, oracle, accu
                 assert nlocal == len(groups) and nfld == 4 * nt
                 bfb.allreduce(send, recv, True)  # CAAS emits (field, partial): the transposed layout
                 return 0
-            c = ca.CAAS(par, len(cells), reducer, accum)
+            c = ca.CAAS(par, len(cells), bfb if typed else reducer, accum)
             for t in types:
                 c.declare_tracer(t, 0)
             c.end_tracer_declarations()
             c.finish_setup()
+            if typed and ngroups == 24000:  # (24000 halves three times into whole subtrees: every rank's part is fusable;
+                assert c.fused_with_bfb()   # of 20011 leaves some ranks own a lone leaf as a subtree of its own and are not)
+            if not typed:
+                assert not c.fused_with_bfb()
             d = [ca.DeviceArray.from_numpy(a) for a in
                  (v.rhom[cells], v.Qm[:, cells], v.Qm_min[:, cells], v.Qm_max[:, cells], v.Qm_prev[:, cells])]
             c.set_rhom(d[0])
@@ -127,6 +134,7 @@ def test_caas_with_bfb_user_reducer_is_decomposition_invariant(gpu, oracle, accu
     want, _ = common.run_oracle_caas(oracle, [ncells], types, v)
     assert common.rel_per_tracer(results[1], want).max() <= 1e-13
     assert R.check(trs, v, results[1], False, verbose=False)[0] == 0
+    assert np.array_equal(results[1], common.caas_bfb_expected(oracle, v, types, ngroups, accum))
 
 
 @pytest.mark.parametrize("nranks,ncell", [(2, 24), (3, 1000), (5, 1000), (8, 1000), (8, 8)])

@@ -95,6 +95,12 @@ def run_ranks(nranks, body, timeout=600, comm=None):
         t.join()
     real = [e for e in errs if e is not None and not isinstance(e, threading.BrokenBarrierError)]
     if real:
+        # (a rank that fails aborts the barrier, and the others then fail inside their next collective: show every rank's
+        # error, the cause is the one that does not mention a collective)
+        import sys
+        for r, e in enumerate(errs):
+            if e is not None:
+                print("run_ranks: rank %d: %s: %s" % (r, type(e).__name__, str(e)[:400].replace("\n", " ")), file=sys.stderr)
         raise real[0]
     if any(errs):
         raise [e for e in errs if e][0]
