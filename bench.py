@@ -76,7 +76,21 @@ def parse():
                          "cst, st, ct, t, nn, cnn in turn (diagnostic)")
     ap.add_argument("--same-gpu", action="store_true",
                     help="rehearsal: every rank uses GPU 0 (needs --comm gloo)")
+    ap.add_argument("--force-rccl", action="store_true",
+                    help="--gpus 1 only: the CDRs get an RCCL communicator of ONE rank instead of the single-rank one, so "
+                         "that every collective of a step really goes through librccl's enqueue path and, on two streams, "
+                         "through the library's cross-stream ordering of the shared communicator (CAAS::run: one "
+                         "ncclAllReduce; QLT::run has no collective on one rank -- see --pretend-ranks)")
+    ap.add_argument("--pretend-ranks", type=int, default=1, metavar="P",
+                    help="--gpus 1 only, rehearsal: run as rank 0 of P -- the tree and the cells are sharded P ways and "
+                         "this process sweeps the first shard, with QLT::run's all-gather + apex and CAAS::run's all-reduce "
+                         "(through RCCL with --force-rccl; the other ranks' all-gather blocks are copies of this rank's). "
+                         "`value` then counts the cells of this shard only; what one GPU can measure of an N-GPU step")
     a = ap.parse_args()
+    if (a.force_rccl or a.pretend_ranks > 1) and a.gpus != 1:
+        ap.error("--force-rccl and --pretend-ranks are rehearsals on ONE GPU (--gpus 1)")
+    if a.pretend_ranks < 1:
+        ap.error("--pretend-ranks must be at least 1")
     if a.check and a.types != "cst":
         ap.error("--check verifies bounds and mass conservation, the properties of cst tracers; mixed types are "
                  "checked against the oracle in tests/")
@@ -245,9 +259,13 @@ def main():
     ncells, nt = a.ncells, a.ntracers
     keep = []  # objects the callbacks refer to
     keep_streams = []
+    # The l2r / r2l buffers: the library takes the first allocation unless asked (CEDR_HIP_PLACE_TRIES); this benchmark
+    # asks for the best of four and reports what the tries found (`placement` in the line).
+    os.environ.setdefault("CEDR_HIP_PLACE_TRIES", "4")
+    nshards = world if world > 1 else a.pretend_ranks  # ranks the tree and the cells are sharded over
 
     def make_cdrs(par, par2):
-        tree = ca.Tree.make_1d(ncells, world, False, False)  # contiguous ownership, balanced
+        tree = ca.Tree.make_1d(ncells, nshards, False, False)  # contiguous ownership, balanced
         qlt = ca.QLT(par, ncells, tree)
         mix = [7, 2, 5, 4, 8, 9]  # cst, s(t), ct, t, nn, cnn
         for i in range(nt):
@@ -256,13 +274,14 @@ def main():
         qlt.finish_setup()
         if a.caas_bfb:
             acc = a.caas_bfb
-            if ncells % (acc * world):
-                raise SystemExit("--caas-bfb %d needs ncells divisible by %d" % (acc, acc * world))
-            btree = ca.Tree.make_1d(ncells // acc, world, False, False)
+            if ncells % (acc * nshards):
+                raise SystemExit("--caas-bfb %d needs ncells divisible by %d" % (acc, acc * nshards))
+            btree = ca.Tree.make_1d(ncells // acc, nshards, False, False)
             bfb = ca.BfbTreeAllReducer(par2, btree, ncells // acc, 4 * nt)
             keep.append((btree, bfb))
-            # CAAS emits (field, partial) = the reducer's transposed layout
-            caas = ca.CAAS(par2, qlt.nlclcells(), lambda s, r, nl, nf: bfb.allreduce(s, r, True), acc)
+            # The reducer object itself is CAAS's UserAllReducer (caas::BfbUserAllReducer): run() fuses its reduce pass
+            # with the first stage of the reducer's tree (CEDR_HIP_CAAS_BFB_FUSE=0: the two separate launches)
+            caas = ca.CAAS(par2, qlt.nlclcells(), bfb, acc)
         else:
             caas = ca.CAAS(par2, qlt.nlclcells())
         for _ in range(nt):
@@ -321,9 +340,19 @@ def main():
             qlt, caas = make_cdrs(par, par2)
             transport = "gloo-host-staged (rehearsal transport, not RCCL)"
     else:
-        par = par2 = ca.Parallel.self_()
+        inner = ca.Parallel.rccl(ca.Parallel.rccl_unique_id(), 0, 1) if a.force_rccl else ca.Parallel.self_()
+        par = par2 = ca.Parallel.rehearsal(inner, a.pretend_ranks) if a.pretend_ranks > 1 else inner
+        keep.append((inner, None))
         qlt, caas = make_cdrs(par, par2)
+        if a.force_rccl or a.pretend_ranks > 1:
+            transport = ("%s communicator of ONE rank%s, %s" %
+                         ("rccl" if a.force_rccl else "single-rank",
+                          (", rehearsing rank 0 of %d (the other ranks' all-gather blocks are copies of this rank's)"
+                           % a.pretend_ranks) if a.pretend_ranks > 1 else "",
+                          "two streams (event ordered)" if a.overlap else "one stream"))
     n = qlt.nlclcells()
+    # cells `value` counts: the whole job's -- except in a rehearsal of rank 0 of P on one GPU, which sweeps (and counts) one shard
+    ncount = n if (world == 1 and a.pretend_ranks > 1) else ncells
 
     rhom, Qm, Qm_min, Qm_max, Qm_prev = gen_inputs(torch, n, nt, 0x5EED0000 + 1000 * 2 + rank, device)
     qlt.set_rhom(rhom)
@@ -354,7 +383,8 @@ def main():
         qlt.set_stream(streams[0].cuda_stream if on else None)
         caas.set_stream(streams[1].cuda_stream if on else None)
         for _, bfb in keep:
-            bfb.set_stream(streams[1].cuda_stream if on else None)  # the reducer runs inside caas.run()
+            if bfb is not None:
+                bfb.set_stream(streams[1].cuda_stream if on else None)  # the reducer runs inside caas.run()
     if streams and world == 1:
         use_streams(True)
 
@@ -380,7 +410,9 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "QLT::run + CAAS::run%s, %d cells x %d cst tracers, balanced 1-D tree, "
                                    "contiguous %d-way sharding" % (" on two concurrent streams" if nstreams == 2 else "",
-                                                                   ncells, nt, world),
+                                                                   ncells, nt, nshards),
+                       "rehearsal": ("rank 0 of %d on one GPU: value counts this shard's %d cells only" % (nshards, n))
+                       if (world == 1 and nshards > 1) else None,
                        "ncells": ncells, "ntracers": nt, "cells_per_gpu": n,
                        "transport": transport, "rccl_nranks": world if (world > 1 and a.comm == "rccl") else 0,
                        "streams": nstreams,
@@ -437,14 +469,16 @@ def main():
 
         def fall_back():
             if rank == 0:
-                line = json_head(2.0 * ncells * nt / (dt_one / a.steps), 1e3 * dt_one / a.steps, 1)
-                line.update(roofline=None, cpu_baseline=None,
+                line = json_head(2.0 * ncount * nt / (dt_one / a.steps), 1e3 * dt_one / a.steps, 1)
+                line.update(roofline=None, cpu_baseline=None, degraded=True,
                             note="the two-stream run (the default program) did not complete over this transport within "
                                  "its time limit; this is the same K steps back to back on ONE stream, measured before it")
                 print(json.dumps(line), file=json_out, flush=True)
             os._exit(0)
         import threading
-        watchdog = threading.Timer(float(os.environ.get("CEDR_BENCH_WATCHDOG_S", "150")), fall_back)
+        # (limit: 150 s, or more for a long run -- 20 x what the one-stream warm-up + K steps just took)
+        limit = max(150.0, 20.0 * dt_one * (1.0 + max(a.warmup, 1) / max(a.steps, 1)))
+        watchdog = threading.Timer(float(os.environ.get("CEDR_BENCH_WATCHDOG_S", limit)), fall_back)
         watchdog.daemon = True
         watchdog.start()
         use_streams(True)
@@ -455,7 +489,9 @@ def main():
         warm_and_check("one stream" if not streams else "two streams", lambda: os._exit(6))
     dt = timed_steps()
     ms_per_step = 1e3 * dt / a.steps
-    value = 2.0 * ncells * nt / (dt / a.steps)
+    value = 2.0 * ncount * nt / (dt / a.steps)
+    if watchdog:  # the two-stream program has completed its timed steps: nothing after this point can stall on it
+        watchdog.cancel()
 
     # Split of the step between the two algorithms (same loop shape, timed apart).
     def timed(fn):
@@ -482,8 +518,6 @@ def main():
     # The same K steps back to back on ONE stream (the shape of rounds 1-2, of the CPU baseline and of the
     # roofline leg below), reported next to the two-stream `value` at every N: the two programs differ only in
     # the overlap, so a regression of the cross-stream ordering over real RCCL shows up as a difference here.
-    if watchdog:
-        watchdog.cancel()
     t_serial = (dt_one / a.steps) if dt_one is not None else (timed(step) if streams else dt / a.steps)
     ca.profile_start()
     for _ in range(a.steps):
@@ -505,7 +539,9 @@ def main():
     alg = {("tree_up_kernel", ntiles1): n * (32.0 * nt + 8), ("qlt_down_kernel", ntiles1): n * (32.0 * nt + 8),
            ("caas_reduce_kernel", n): n * nt * 40.0, ("caas_finish_kernel", n): n * nt * 24.0,
            # user-reducer variant: the same streams + 4 partial sums per group of caas_bfb cells
-           ("caas_reduce_accum_kernel", n): n * nt * (40.0 + 32.0 / max(a.caas_bfb, 1))}
+           ("caas_reduce_accum_kernel", n): n * nt * (40.0 + 32.0 / max(a.caas_bfb, 1)),
+           # ... fused with the BFB reducer's first stage: nothing but the cells' own streams (+ KBs of tile outputs)
+           ("caas_reduce_bfb_kernel", n): n * nt * 40.0}
     kernels = []
     for (name, aux), (cnt, tot) in sorted(per.items(), key=lambda kv: -kv[1][1]):
         avg_ms = tot / cnt
@@ -519,11 +555,17 @@ def main():
     # this same command (profiles/rNN_traffic.json, made by tools/profile_traffic.sh; the newest
     # round's file whose configuration matches), and the line says so in roofline.traffic_source.
     traffic_source = None
+    traffic_refused = []
+    ksha = ca.kernels_sha256()
     for cand in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles"))
                         if f.startswith("r") and f.endswith("_traffic.json")), reverse=True):
         try:
             tr = json.load(open(os.path.join(ROOT, "profiles", cand)))
-            if world != 1 or tr["config"] != {"ncells": ncells, "ntracers": nt}:
+            if world != 1 or a.pretend_ranks > 1 or tr["config"] != {"ncells": ncells, "ntracers": nt}:
+                continue
+            if tr.get("kernels_sha256") != ksha:
+                # counters of OTHER kernel code say nothing about this run's: refused, and the line says so
+                traffic_refused.append("profiles/%s (kernels_sha256 %s)" % (cand, str(tr.get("kernels_sha256"))[:12]))
                 continue
             for k in kernels:
                 t = tr["kernels"].get(k["kernel"])
@@ -541,6 +583,7 @@ def main():
         roofline = dict(bound="hbm", kernel=dom["kernel"], achieved=dom["achieved_GBs"],
                         peak=HBM_PEAK_GBS, unit="GB/s", frac=dom["frac"], traffic=dom.get("traffic"),
                         traffic_source=traffic_source if dom.get("traffic") is not None else None,
+                        traffic_refused=traffic_refused or None,
                         avg_ms=dom["avg_ms"], algorithmic_bytes_per_launch=dom["algorithmic_bytes"],
                         launch="first stage: %d workgroups (tiles)" % dom["launch"],
                         rocprof="every stage runs the same sweep kernels (qlt_down_sp_kernel / tree_up_micro_kernel),"
@@ -623,13 +666,33 @@ def main():
             cpu = dict(value=None, unit="cell-tracer-updates/s", cores=0, kind="port",
                        sample="failed: %r" % (e,))
 
+    caas_fused = bool(a.caas_bfb) and caas.fused_with_bfb()
+    caas_bytes = 64.0 + (64.0 / a.caas_bfb if (a.caas_bfb and not caas_fused) else 0.0)
+    # what QLT::finish_setup's placement tries found: time of the first-stage sweeps over every candidate allocation
+    rep = qlt.placement_report()
+    placement = {"report": rep, "tries_env": os.environ.get("CEDR_HIP_PLACE_TRIES")}
+    for part in rep.split(";"):
+        w = part.split()
+        if len(w) > 2 and w[1] == "ms:" and "kept" in w:
+            ms = [float(x) for x in w[2:w.index("kept")]]
+            placement[w[0]] = {"candidates_ms": ms, "kept": int(w[w.index("kept") + 1]),
+                               "spread": (max(ms) - min(ms)) / min(ms) if ms else None}
     if rank == 0:
         line = json_head(value, ms_per_step, 2 if streams else 1)
         line.update({
-            "serial": {"ms_per_step": 1e3 * t_serial, "value": 2.0 * ncells * nt / t_serial,
+            "serial": {"ms_per_step": 1e3 * t_serial, "value": 2.0 * ncount * nt / t_serial,
                        "note": "the same steps with QLT::run and CAAS::run back to back on one stream"},
-            "qlt": {"ms_per_run": 1e3 * t_qlt, "updates_per_s": ncells * nt / t_qlt},
-            "caas": {"ms_per_run": 1e3 * t_caas, "updates_per_s": ncells * nt / t_caas},
+            # whole-run fractions of the HBM roofline: algorithmic bytes per cell-tracer x this GPU's cells x
+            # tracers / the run's time / 8 TB/s (QLT: every cell record read on the way up and again on the way down + the
+            # result written, rhom twice per cell; CAAS: 40 B in the reduce pass + 24 B in the finish pass, + the
+            # per-group partial sums written and read back when a BFB reducer is NOT fused with the reduce pass)
+            "qlt": {"ms_per_run": 1e3 * t_qlt, "updates_per_s": ncount * nt / t_qlt,
+                    "bytes_per_cell_tracer": 64.0 + 16.0 / nt,
+                    "frac": (64.0 + 16.0 / nt) * n * nt / t_qlt / 1e9 / HBM_PEAK_GBS},
+            "caas": {"ms_per_run": 1e3 * t_caas, "updates_per_s": ncount * nt / t_caas,
+                     "bytes_per_cell_tracer": caas_bytes, "frac": caas_bytes * n * nt / t_caas / 1e9 / HBM_PEAK_GBS,
+                     "fused_with_bfb_reducer": caas_fused},
+            "placement": placement, "kernels_sha256": ksha,
             "pack_unpack": pack, "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu,
         })
         if ok is not None:

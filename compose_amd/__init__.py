@@ -68,6 +68,7 @@ _SIGS = {
     "cedr_parallel_create_self": (_vp, []),
     "cedr_rccl_get_unique_id": (C.c_int, [_vp]),
     "cedr_parallel_create_rccl": (_vp, [_vp, C.c_int, C.c_int]),
+    "cedr_parallel_create_rehearsal": (_vp, [_vp, C.c_int]),
     "cedr_parallel_create_callbacks": (_vp, [C.c_int, C.c_int, ALLGATHER_FN, ALLREDUCE_FN, _vp]),
     "cedr_parallel_create_callbacks_p2p": (_vp, [C.c_int, C.c_int, ALLGATHER_FN, ALLREDUCE_FN, EXCHANGE_FN, _vp]),
     "cedr_parallel_exchange": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
@@ -108,6 +109,7 @@ _SIGS = {
     "cedr_qlt_gci2lci": (C.c_int, [_vp, C.c_int]),
     "cedr_qlt_run": (C.c_int, [_vp]),
     "cedr_qlt_set_stream": (C.c_int, [_vp, _vp]),
+    "cedr_qlt_placement_report": (C.c_char_p, [_vp]),
     "cedr_qlt_sweep_down_event": (_vp, [_vp]),
     "cedr_qlt_sweep_mid_event": (_vp, [_vp]),
     "cedr_stream_wait_event": (C.c_int, [_vp, _vp]),
@@ -374,6 +376,13 @@ class Parallel:
     def rccl(unique_id, rank, size):
         buf = C.create_string_buffer(bytes(unique_id), 128)
         return Parallel(lib().cedr_parallel_create_rccl(buf, rank, size))
+
+    @staticmethod
+    def rehearsal(inner, pretended_size):
+        """Rank 0 of pretended_size ranks over `inner`, a Parallel of ONE real rank (self_() or rccl(id, 0, 1)):
+        collectives run through `inner` for real, the other ranks' all-gather blocks are copies of this rank's.
+        What one GPU can run of an N-GPU job (measurements, tests)."""
+        return Parallel(lib().cedr_parallel_create_rehearsal(inner.h, int(pretended_size)), keep=inner)
 
     @staticmethod
     def rccl_unique_id():
@@ -752,6 +761,10 @@ class QLT(_CDR):
         keys = ["trcr2prob", "bidx2trcr", "trcr2bidx", "trcr2bl2r", "trcr2br2l",
                 "prob2trcrptr", "prob2bl2r", "prob2br2l"]
         return dict(zip(keys, a))
+
+    def placement_report(self):
+        """What finish_setup did about the placement of its own buffers (CEDR_HIP_PLACE_TRIES)."""
+        return (lib().cedr_qlt_placement_report(self.h) or b"").decode()
 
     def nodesets(self):
         return dump_nodesets(lib().cedr_qlt_nodesets(self.h))

@@ -49,6 +49,13 @@ void BfbTreeAllReducerHip::init (const mpi::Parallel::Ptr& p, const tree::FlatTr
   nfield_ = nfield;
   plan::Options popt;
   engine::plan_options(popt);
+  // The first stage's tiles: QLT cuts them to two LDS levels because its root->leaves sweep is bound by the chain of
+  // dependent levels; this reducer only sweeps leaves->root, where a level costs a wave one LDS round trip, and a cut
+  // first stage means one more (small, latency-bound) stage = launch before the top tile (round 5, 375k leaves x 160
+  // fields: CAAS::run with this reducer 0.654 -> 0.620 ms fused, 0.889 -> 0.870 ms as separate launches; as rank 0 of 8
+  // 0.113 -> 0.108 ms). CEDR_HIP_BFB_CUT = LDS levels kept (default 0 = all).
+  popt.micro_cut = 0;
+  if (const char* e = std::getenv("CEDR_HIP_BFB_CUT")) popt.micro_cut = std::atoi(e);
   eng_.reset(new engine::TreeEngine(p, tree, *ns_, popt));
   m_.reset(new Impl());
 }

@@ -56,6 +56,12 @@ int cedr_rccl_get_unique_id (void* id) { return mpi::rccl_get_unique_id(id); }
 void* cedr_parallel_create_rccl (const void* id, int rank, int size) {
   CEDR_TRY return new ParallelBox{mpi::make_parallel_rccl(id, rank, size)}; CEDR_CATCH(nullptr)
 }
+void* cedr_parallel_create_rehearsal (void* inner, int pretended_size) {
+  CEDR_TRY
+  cedr_throw_if( ! inner, "cedr_parallel_create_rehearsal needs an inner Parallel");
+  return new ParallelBox{mpi::make_parallel_rehearsal(static_cast<ParallelBox*>(inner)->p, pretended_size)};
+  CEDR_CATCH(nullptr)
+}
 void* cedr_parallel_create_callbacks (int rank, int size, cedr_allgather_fn ag,
                                       cedr_allreduce_sum_fn ar, void* user) {
   CEDR_TRY
@@ -225,6 +231,7 @@ int cedr_qlt_gci2lci (void* h, int gci) { CEDR_TRY return Q(h).gci2lci(gci); CED
 int cedr_qlt_run (void* h) { CEDR_TRY Q(h).run(); return 0; CEDR_CATCH(-1) }
 int cedr_qlt_set_stream (void* h, cedr_stream_t s) { Q(h).set_stream(s); return 0; }
 void* cedr_qlt_sweep_down_event (void* h) { CEDR_TRY return Q(h).sweep_down_event(); CEDR_CATCH(nullptr) }
+const char* cedr_qlt_placement_report (void* h) { return Q(h).placement_report().c_str(); }
 void* cedr_qlt_sweep_mid_event (void* h) { CEDR_TRY return Q(h).sweep_mid_event(); CEDR_CATCH(nullptr) }
 int cedr_stream_wait_event (cedr_stream_t s, void* ev) {
   return static_cast<int>(hipStreamWaitEvent(static_cast<hipStream_t>(s), static_cast<hipEvent_t>(ev), 0));

@@ -2449,7 +2449,8 @@ constexpr int kAccumSub = CEDR_CAAS_ACCUM_SUB;  // cells per sub-block (upper bo
 constexpr int kAccumNsb = CEDR_CAAS_ACCUM_NSB;     // sub-blocks per workgroup
 constexpr size_t kBfbFusedMaxLds = 80*1024;        // caas_reduce_bfb_kernel: at least two workgroups per CU
 constexpr int kBfbFusedWgs = 8192;                 // ... workgroups wanted per launch (tracers are dealt to reach it)
-constexpr int kBfbFusedWgsP2 = 16384;              // the same for caas_reduce_bfb_p2_kernel
+constexpr int kBfbFusedWgsP2 = 1 << 30;            // caas_reduce_bfb_p2_kernel: one tracer per workgroup, like caas_reduce_kernel
+                                                   // (1.5M x 40, 2048 tiles: 0.390 ms; two / five / ten per workgroup: 0.423 / 0.439 / 0.445)
 template <int VEC>  // 2: 16-byte accesses, two cells per thread and pass (needs n and sb even, 16-byte aligned rows)
 __global__ __launch_bounds__(kBlock)
 void caas_reduce_accum_lds_kernel (const int32_t* __restrict__ probs, const int nt, const int n,
@@ -2774,8 +2775,11 @@ __device__ __forceinline__ double row_shr1 (const double x) {
 // enough, and nothing is parked: ~10 KB of LDS and ~50 VGPRs per workgroup instead of 35 KB and 112, i.e. the
 // occupancy of caas_reduce_kernel, whose streaming rate this kernel is built to keep (at 4 workgroups per CU
 // that kernel itself drops from 0.383 to 0.423 ms, at 3 to 0.50: profiles/r05_experiments.md).
+#ifndef CEDR_BFB_P2_WAVES
+# define CEDR_BFB_P2_WAVES 7  // waves per SIMD the register allocation aims at (8 = 64 VGPRs: two spills, +4 %)
+#endif
 template <int NP>
-__global__ __launch_bounds__(kBlock)
+__global__ __launch_bounds__(kBlock, CEDR_BFB_P2_WAVES)
 void caas_reduce_bfb_p2_kernel (const int32_t* __restrict__ probs, const int nt, const int n,
                                 const int need_conserve, const int lg,
                                 double* __restrict__ d, const double* __restrict__ qm_src,
@@ -2818,18 +2822,28 @@ void caas_reduce_bfb_p2_kernel (const int32_t* __restrict__ probs, const int nt,
   // the compiler waited for the first pass before it asked for the second). A tracer without Qm_prev re-reads its Qm
   // row for the second sum (cache hits).
   auto load = [&] (const int k, const int b0, Regs& r) {
-    const d2* const vin = reinterpret_cast<const d2*>((qm_src ? qm_src + k*N : d + (1 + k)*N) + cell0);
-    const d2* const vlo = reinterpret_cast<const d2*>(d + (1 + nt + k)*N + cell0);
-    const d2* const vhi = reinterpret_cast<const d2*>(d + (1 + 2*static_cast<size_t>(nt) + k)*N + cell0);
-    const d2* const vpv = (need_conserve && (probs[k] & CONSERVE) != 0) ?
-      reinterpret_cast<const d2*>(d + (1 + 3*static_cast<size_t>(nt) + k)*N + cell0) : vin;
+    // (scalar row bases + one 32-bit byte offset per pass: no 64-bit address arithmetic per load, fewer registers)
+    const double* const vin = (qm_src ? qm_src + k*N : d + (1 + k)*N) + cell0;
+    const double* const vlo = d + (1 + nt + k)*N + cell0;
+    const double* const vhi = d + (1 + 2*static_cast<size_t>(nt) + k)*N + cell0;
+    const double* const vpv = (need_conserve && (probs[k] & CONSERVE) != 0) ?
+      d + (1 + 3*static_cast<size_t>(nt) + k)*N + cell0 : vin;
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
+#ifdef CEDR_BFB_P2_CLAMP  // (experiment: threads past the tile's last pair re-read it instead of skipping the loads)
       const int i2 = min(b0 + static_cast<int>(threadIdx.x) + kBlock*p, cnt2 - 1);
-      asm volatile("global_load_dwordx4 %0, %1, off nt" : "=&v"(r.q[p]) : "v"(vin + i2) : "memory");
-      asm volatile("global_load_dwordx4 %0, %1, off nt" : "=&v"(r.lo[p]) : "v"(vlo + i2) : "memory");
-      asm volatile("global_load_dwordx4 %0, %1, off nt" : "=&v"(r.hi[p]) : "v"(vhi + i2) : "memory");
-      asm volatile("global_load_dwordx4 %0, %1, off nt" : "=&v"(r.pv[p]) : "v"(vpv + i2) : "memory");
+      const bool on = true;
+#else
+      const int i2 = b0 + static_cast<int>(threadIdx.x) + kBlock*p;
+      const bool on = i2 < cnt2;
+#endif
+      const int off = i2 << 4;
+      if (on) {  // (the compiler does not see the loads: no wait ends up between the passes)
+        asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=&v"(r.q[p]) : "v"(off), "s"(vin) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=&v"(r.lo[p]) : "v"(off), "s"(vlo) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=&v"(r.hi[p]) : "v"(off), "s"(vhi) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=&v"(r.pv[p]) : "v"(off), "s"(vpv) : "memory");
+      }
     }
   };
   auto wait_regs = [&] (Regs& r) {

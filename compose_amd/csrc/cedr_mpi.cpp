@@ -181,7 +181,40 @@ struct CallbackComm : public Comm {
   }
 };
 
+// ------------------------------------------------------------------- rehearsal
+// Rank 0 of 'size' pretended ranks over a communicator of ONE real rank: what a single GPU can run of an N-GPU
+// job. A collective goes through the inner communicator for real (RcclComm of one rank: librccl's own enqueue
+// path and the cross-stream ordering events of this file) and the other ranks' blocks of an all-gather are copies
+// of this rank's. Measurement and test tool (bench.py --pretend-ranks, tools/): the RESULTS are those of a job in
+// which every rank holds this rank's data, not of any real decomposition.
+struct RehearsalComm : public Comm {
+  std::shared_ptr<Comm> inner_;
+  int size_;
+  RehearsalComm (const std::shared_ptr<Comm>& inner, int size) : inner_(inner), size_(size) {}
+  int rank () const override { return 0; }
+  int size () const override { return size_; }
+  int allgather (const Real* send, Real* recv, size_t count, hipStream_t s) override {
+    const int e = inner_->allgather(send, recv, count, s);
+    if (e) return e;
+    for (int r = 1; r < size_; ++r) {
+      const hipError_t h = hipMemcpyAsync(recv + static_cast<size_t>(r)*count, send, count*sizeof(Real),
+                                          hipMemcpyDeviceToDevice, s);
+      if (h != hipSuccess) return static_cast<int>(h);
+    }
+    return 0;
+  }
+  int allreduce_sum (const Real* send, Real* recv, size_t count, hipStream_t s) override {
+    return inner_->allreduce_sum(send, recv, count, s);
+  }
+};
+
 }  // namespace
+
+Parallel::Ptr make_parallel_rehearsal (const Parallel::Ptr& inner, int pretended_size) {
+  cedr_throw_if( ! inner || inner->size() != 1, "a rehearsal communicator wraps a communicator of one rank");
+  cedr_throw_if(pretended_size < 1, "pretended_size must be at least 1");
+  return std::make_shared<Parallel>(std::make_shared<RehearsalComm>(inner->comm().ptr(), pretended_size));
+}
 
 Parallel::Ptr make_parallel () {
   return std::make_shared<Parallel>(std::make_shared<SelfComm>());

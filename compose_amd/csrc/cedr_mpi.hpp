@@ -88,6 +88,12 @@ Parallel::Ptr make_parallel (const std::shared_ptr<Comm>& comm);
 int rccl_get_unique_id (void* unique_id_128B);
 Parallel::Ptr make_parallel_rccl (const void* unique_id_128B, int rank, int size);
 
+// Rehearsal of an N-rank job on ONE GPU: rank 0 of 'pretended_size' ranks over 'inner', a communicator of one real
+// rank (make_parallel() or make_parallel_rccl(id, 0, 1)). Every collective runs through 'inner' for real -- with
+// RCCL inside: librccl's enqueue path and this library's cross-stream ordering of the shared communicator -- and the
+// other ranks' blocks of an all-gather are copies of this rank's. For measurements and tests only.
+Parallel::Ptr make_parallel_rehearsal (const Parallel::Ptr& inner, int pretended_size);
+
 // Callback communicator: the host application supplies the two collectives.
 typedef int (*AllgatherFn) (void* user, const Real* send, Real* recv, size_t count, hipStream_t);
 typedef int (*AllreduceSumFn) (void* user, const Real* send, Real* recv, size_t count, hipStream_t);

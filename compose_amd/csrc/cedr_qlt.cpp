@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <string>
 #include <cstdio>
 #include <cstdlib>
 
@@ -46,6 +47,7 @@ struct QLTHip::Impl {
   std::vector<Int> packed_tracers;  // caller indices of the t-only tracers
   hipEvent_t down_ev = nullptr;     // see QLTHip::sweep_down_event
   hipEvent_t mid_ev = nullptr;      // see QLTHip::sweep_mid_event
+  std::string placement;            // see QLTHip::placement_report
   ~Impl () { if (down_ev) (void) hipEventDestroy(down_ev); if (mid_ev) (void) hipEventDestroy(mid_ev); }
 };
 
@@ -268,9 +270,13 @@ void QLTHip::finish_setup () {
     // kept meanwhile, so that each gets other memory -- and the one over which the two first-stage sweeps together
     // run fastest is kept (on zeros: the sweeps' memory traffic does not depend on the data); then the same for the
     // r2l buffer with the root->leaves sweep.
-    // CEDR_HIP_PLACE_TRIES (default 4; 1 = take the first). Callers who bring their own memory are not affected.
+    // CEDR_HIP_PLACE_TRIES = allocations tried (default 1 = take the first: a library that grabs several transient
+    // copies of its largest buffer and times ~30 launches in finish_setup, for an effect whose cause is unknown, should
+    // be asked to; bench.py asks for 4 and reports what happened, placement_report()). Callers who bring their own
+    // memory are not affected.
     const char* const tv = std::getenv("CEDR_HIP_PLACE_TRIES");
-    const int tries = tv ? std::atoi(tv) : 4;
+    const int tries = tv ? std::atoi(tv) : 1;
+    d.placement = "tries " + std::to_string(tries < 1 ? 1 : tries);
     if (tries > 1) {
       const int32_t nf = md_.prob2bl2r[MetaData::nprobtypes];
       const size_t nr2l = d.r2l_own.size();
@@ -287,7 +293,11 @@ void QLTHip::finish_setup () {
         timed = true;
         float best = is_l2r ? score(own.data(), d.r2l_own.data(), true) : score(d.l2r_own.data(), own.data(), false);
         if (verbose) std::fprintf(stderr, "cedr: %s placement try 0: %.4f ms\n", is_l2r ? "l2r" : "r2l", best);
-        if (best <= 0) return false;
+        if (best <= 0) { d.placement += is_l2r ? "; l2r: first stage too small to time" : "; r2l: not timed"; return false; }
+        char buf[64];
+        std::snprintf(buf, sizeof(buf), "; %s ms: %.4f", is_l2r ? "l2r" : "r2l", best);
+        d.placement += buf;
+        int kept = 0;
         std::vector<std::unique_ptr<dev::Buffer<Real> > > parked;
         for (int t = 1; t < tries; ++t) {
           // Another candidate only while the device keeps twice its size free afterwards: the tries are a transient
@@ -306,9 +316,12 @@ void QLTHip::finish_setup () {
           const float ms = is_l2r ? score(c->data(), d.r2l_own.data(), true) : score(d.l2r_own.data(), c->data(), false);
           if (verbose) std::fprintf(stderr, "cedr: %s placement try %d: %.4f ms (best so far %.4f)\n",
                                     is_l2r ? "l2r" : "r2l", t, ms, best);
-          if (ms > 0 && ms < 0.995f*best) { best = ms; c->swap(own); }
+          std::snprintf(buf, sizeof(buf), " %.4f", ms);
+          d.placement += buf;
+          if (ms > 0 && ms < 0.995f*best) { best = ms; c->swap(own); kept = t; }
           parked.push_back(std::move(c));
         }
+        d.placement += " kept " + std::to_string(kept);
         return true;
       };
       // (The sweeps are timed on zeros: every node problem then takes its quick exit, so the root->leaves time is
@@ -339,6 +352,7 @@ Int QLTHip::get_num_tracers () const { return static_cast<Int>(md_.trcr2prob.siz
 const QLTHip::DeviceOp& QLTHip::get_device_op () { return o; }
 
 void QLTHip::set_stream (hipStream_t stream) { d_->stream = stream; }
+const std::string& QLTHip::placement_report () const { return d_->placement; }
 
 hipEvent_t QLTHip::sweep_down_event () {
   if ( ! d_->down_ev) cedr_hip_check(hipEventCreateWithFlags(&d_->down_ev, hipEventDisableTiming));

@@ -5,6 +5,7 @@
 #define COMPOSE_AMD_CEDR_QLT_HPP
 
 #include <memory>
+#include <string>
 #include <vector>
 
 #include "cedr_cdr.hpp"
@@ -118,6 +119,9 @@ public:
   // still packed, by a small kernel inside run(). rhom == nullptr switches back.
   void bind_arrays(const Real* rhom, const Real* Qm, const Real* Qm_min, const Real* Qm_max,
                    const Real* Qm_prev, Real* Qm_out);
+  // What finish_setup did about the placement of the buffers it allocated itself (CEDR_HIP_PLACE_TRIES): "tries N;
+  // l2r ms: <time of both first-stage sweeps over every candidate> kept <index>; r2l ms: ... kept <index>".
+  const std::string& placement_report () const;
   const MetaData& metadata () const { return md_; }
   const tree::NodeSets& nodesets () const { return *ns_; }
   const engine::TreeEngine& tree_engine () const { return *eng_; }

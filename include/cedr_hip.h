@@ -272,6 +272,10 @@ void* cedr_parallel_create_self(void);
  * rank, distributed by the launcher. */
 int cedr_rccl_get_unique_id(void* unique_id_128B);
 void* cedr_parallel_create_rccl(const void* unique_id_128B, int rank, int size);
+/* Rehearsal of an N-rank job on ONE GPU (measurements, tests): rank 0 of pretended_size ranks over `inner`, a
+ * Parallel of one real rank (cedr_parallel_create_self or cedr_parallel_create_rccl(id, 0, 1)); collectives go
+ * through `inner` for real, the other ranks' blocks of an all-gather are copies of this rank's. */
+void* cedr_parallel_create_rehearsal(void* inner_parallel, int pretended_size);
 /* Host-application transport (e.g. GPU-aware MPI). Buffers are device memory. */
 typedef int (*cedr_allgather_fn)(void* user, const double* send, double* recv, size_t count,
                                  cedr_stream_t stream);
@@ -355,6 +359,10 @@ void* cedr_qlt_sweep_down_event(void* qlt);
  * sweep is a short series of small, latency-bound launches that leave most of the GPU idle */
 void* cedr_qlt_sweep_mid_event(void* qlt);
 int cedr_stream_wait_event(cedr_stream_t stream, void* event);
+/* What finish_setup did about where its own l2r / r2l buffers live (CEDR_HIP_PLACE_TRIES = allocations tried, default 1):
+ * "tries N; l2r ms: t0 t1 ... kept i; r2l ms: ... kept j" (time of the first-stage sweeps over each candidate). Valid
+ * while the QLT lives. */
+const char* cedr_qlt_placement_report(void* qlt);
 /* DeviceOp for C callers: the values a device kernel needs to do set/get itself. */
 typedef struct {
   double* l2r_data; double* r2l_data; int64_t stride;

@@ -127,3 +127,69 @@ def test_bench_rccl_failure_is_a_failed_run(gpu):
     assert res.returncode == 0, res.stdout[-1500:] + res.stderr[-1500:]
     assert d["check_ok"] is True and d["config"]["rccl_nranks"] == 0
     assert d["config"]["transport"].startswith("gloo-host-staged")
+
+
+@pytest.mark.parametrize("extra,streams", [([], 2), (["--serial"], 1)])
+@pytest.mark.parametrize("bfb", [[], ["--caas-bfb", "4"]])
+def test_bench_force_rccl_rank_0_of_8(gpu, extra, streams, bfb):
+    """Real librccl in the loop on one GPU: bench.py --force-rccl --pretend-ranks 8 runs the step as rank 0 of 8 over an
+    RCCL communicator of one rank -- QLT::run's ncclAllGather + apex and CAAS::run's ncclAllReduce (or the BFB
+    reducer's all-gather) are really enqueued, on two streams through the library's cross-stream ordering events
+    (reference cedr_qlt.cpp:327-337,432-439, cedr_caas.cpp:203-209 are the MPI calls they replace). The results pass the
+    checks, and the line says what it is."""
+    res, d = _bench(["--steps", "3", "--warmup", "1", "--ncells", "240000", "--ntracers", "6", "--check",
+                     "--no-cpu-baseline", "--force-rccl", "--pretend-ranks", "8"] + extra + bfb)
+    assert res.returncode == 0, res.stdout[-1500:] + res.stderr[-1500:]
+    assert d["n_gpus"] == 1 and d["check_ok"] is True and d["config"]["streams"] == streams
+    assert d["config"]["transport"].startswith("rccl communicator of ONE rank, rehearsing rank 0 of 8")
+    assert d["config"]["cells_per_gpu"] == 30000 and "rank 0 of 8" in d["config"]["rehearsal"]
+    assert abs(d["value"] - 2 * 30000 * 6 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    assert d["kernels_sha256"] == gpu.kernels_sha256() and len(d["kernels_sha256"]) == 64
+    assert 0 < d["qlt"]["frac"] < 1 and 0 < d["caas"]["frac"] < 1 and d["placement"]["tries_env"] == "4"
+    if bfb:
+        assert d["caas"]["fused_with_bfb_reducer"] is True and d["caas"]["bytes_per_cell_tracer"] == 64.0
+
+
+def test_rehearsal_over_rccl_matches_the_stub_bitwise(gpu):
+    """QLT as rank 0 of 8 over the rehearsal communicator: the same bits whether its inner communicator is the
+    single-rank one (plain copies) or an RCCL communicator of one rank, on one stream and with the CAAS of the same
+    communicator running on a second stream (the collectives of one communicator are then ordered by events)."""
+    import torch
+    ca = gpu
+    n, nt, P = 160000, 5, 8
+    sys.path.insert(0, ROOT)
+    import bench
+    dev = torch.device("cuda", 0)
+    rhom, Qm, lo, hi, prev = bench.gen_inputs(torch, n // P, nt, 99, dev)
+    outs = []
+    for inner_kind in ("self", "rccl"):
+        for two_streams in (False, True):
+            inner = ca.Parallel.self_() if inner_kind == "self" else ca.Parallel.rccl(ca.Parallel.rccl_unique_id(), 0, 1)
+            par = ca.Parallel.rehearsal(inner, P)
+            assert par.size() == P and par.rank() == 0
+            q = ca.QLT(par, n, ca.Tree.make_1d(n, P, False, False))
+            c = ca.CAAS(par, n // P)
+            for x in (q, c):
+                for _ in range(nt):
+                    x.declare_tracer(7, 0)
+                x.end_tracer_declarations()
+                x.finish_setup()
+            assert q.nlclcells() == n // P
+            s = [torch.cuda.Stream(device=dev) for _ in range(2)] if two_streams else None
+            if s:
+                q.set_stream(s[0].cuda_stream)
+                c.set_stream(s[1].cuda_stream)
+            torch.cuda.synchronize()
+            q.set_rhom(rhom); q.set_Qm(Qm, lo, hi, prev)
+            c.set_rhom(rhom); c.set_Qm(Qm, lo, hi, prev); c.set_Qm_source(Qm)
+            for _ in range(3):
+                q.run()
+                c.run()
+            oq, oc = torch.empty_like(Qm), torch.empty_like(Qm)
+            q.get_Qm(oq); c.get_Qm(oc)
+            torch.cuda.synchronize()
+            outs.append((oq, oc))
+            assert bool(((oq >= lo) & (oq <= hi)).all()) and bool(((oc >= lo) & (oc <= hi)).all())
+            del q, c
+    for oq, oc in outs[1:]:
+        assert torch.equal(oq, outs[0][0]) and torch.equal(oc, outs[0][1])
