@@ -3284,6 +3284,10 @@ int cedr_hip_qlt_down_rows (const cedr_hip_qlt_layout* lay, const cedr_hip_stage
     static const bool sp_on = [] { const char* v = std::getenv("CEDR_HIP_DOWN_SP"); return ! v || std::atoi(v) != 0; }();
     const bool sp = (lay->flags & CEDR_QLT_ALL_SHAPEPRESERVE) && sp_on;
     int tw = (sp || 0.7*((nt + 3)/4) < 1.0*((nt + 7)/8)) ? 1 : 2;
+    // (experiment, round 5: launches of at most CEDR_HIP_SP_TW2_MAX_TILES tiles -- one round of workgroups, bound by a
+    // chunk's chain and not by occupancy -- take two tracers per wave, i.e. half the chunks; default 0 = none)
+    static const int tw2_max = [] { const char* v = std::getenv("CEDR_HIP_SP_TW2_MAX_TILES"); return v ? std::atoi(v) : 0; }();
+    if (sp && st->ntiles <= tw2_max) tw = 2;
     if (const char* e = std::getenv("CEDR_HIP_MICRO_TW")) tw = std::atoi(e) == 1 ? 1 : 2;
     const int TTm = kNW*tw;
     const size_t ldsm = sizeof(double)*(meta_doubles(st) + 3*mn + kCellRho*kWave +

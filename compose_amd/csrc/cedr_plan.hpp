@@ -128,8 +128,13 @@ struct Options {
   int32_t max_tile_leaves = 128;  // inputs per tile (bounded by the kernels' LDS use)
   bool micro = true;              // first local stage uses micro tiles (64 x <= 3 leaves)
   bool micro_all = true;          // ... and so does every later stage, over the previous one's outputs
-  int32_t micro_cut = 2;          // local levels kept per micro tile of the FIRST stage (0 = keep all)
-  int32_t micro_cut2 = 3;         // the same for the second stage (micro_all only; 0 = keep all; round 4: 3 instead of 2
+  int32_t micro_cut = 3;          // local levels kept per micro tile of the FIRST stage (0 = keep all). Round 5: 3 instead of 2,
+                                  // with micro_cut2 = 4 (profiles/r05_experiments.md): at 1.5M cells x 40 tracers the first-stage
+                                  // root->leaves launch walks one level more per chunk (+0.03-0.04 ms), the leaves->root one writes
+                                  // half the output lines (-0.01 to -0.02 ms), the second stage halves (-0.04 ms) and the third
+                                  // disappears into the top tile: QLT::run -1 to -2 %, the two-stream step -1.5 to -5 %; neutral
+                                  // at the 187.5k-cell shard
+  int32_t micro_cut2 = 4;         // the same for the second stage (micro_all only; 0 = keep all; round 4: 3 instead of 2
                                   // -- the later stages' tiles keep one level more, the top tile one level fewer: QLT::run
                                   // -0.3 % at 1.5M cells, -2.5 % at the 187.5k-cell shard, profiles/r04_experiments.md 8): cutting
                                   // it moves tree levels from the second to the third stage, which

@@ -325,7 +325,7 @@ int main () {
                 if ( ! micro && cut != 3) continue;
                 plan::Options o;
                 o.max_tile_leaves = tile; o.micro = micro != 0; o.micro_cut = cut;
-                o.micro_cut2 = cut == 2 ? 2 : (cut == 5 ? 3 : 0);
+                o.micro_cut2 = cut == 2 ? 2 : (cut == 5 ? 3 : (cut == 3 ? 4 : 0));
                 std::snprintf(ctx, sizeof(ctx), "nc %d P %d pseudorandom %d imbalanced %d tile %d micro %d cut %d",
                               nc, P, pr, imb, tile, micro, cut);
                 check(t, nc, P, o, ctx);
