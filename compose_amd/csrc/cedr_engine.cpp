@@ -1,6 +1,8 @@
 #include "cedr_engine.hpp"
 
 #include <algorithm>
+#include <atomic>
+#include <string>
 #include <cstdio>
 #include <cstdlib>
 
@@ -44,9 +46,17 @@ void plan_options (plan::Options& o) {
     const int64_t room = static_cast<int64_t>(lds) - 10*1024;
     int32_t cap = 2;
     while (cap < 2048 && 72*static_cast<int64_t>(2*cap - 1) <= room) cap *= 2;
+    const int32_t asked = o.top_max_inputs;
     if (72*static_cast<int64_t>(cap - 1) > room) o.fused_top = false;           // not even a 2-input tile
     else if (cap < 256) o.fused_top = false;                                     // too small to replace a stage
     else if (o.top_max_inputs > cap) o.top_max_inputs = cap;
+    // A smaller or missing top tile changes every plan of the process: say so once, not only under a verbose knob
+    // (a gfx950 grants 160 KB; a runtime that reports 64 KB there would otherwise change the plans silently).
+    static std::atomic<bool> said(false);
+    if (( ! o.fused_top || o.top_max_inputs < asked) && ! said.exchange(true))
+      std::fprintf(stderr, "cedr (hip): device %d grants %d B of LDS per workgroup: the fused top tile is %s "
+                   "(asked for up to %d inputs)\n", dev, lds,
+                   o.fused_top ? ("limited to " + std::to_string(o.top_max_inputs) + " inputs").c_str() : "off", asked);
   } else {
     (void) hipGetLastError();
   }
@@ -82,6 +92,10 @@ void DeviceStage::upload (const plan::Stage& st) {
       if (st.tiles[i].nleaf != 64 || st.tiles[i].micro_off != static_cast<int32_t>(64*i)) uni = false;
     if (uni) h.flags |= CEDR_STAGE_UNIFORM64;
   }
+  // Tail-split knobs of the first-stage launches (cedr_kernels.hip tail_split), read here once per stage
+  if (const char* e = std::getenv("CEDR_HIP_TAIL"))
+    h.flags |= CEDR_STAGE_TAIL_SET | ((std::max(0, std::min(127, std::atoi(e)))) << 16);
+  if (const char* e = std::getenv("CEDR_HIP_TAIL_ROUNDS")) h.flags |= (std::max(0, std::min(127, std::atoi(e)))) << 24;
   if (st.top && st.tiles.size() == 1) {
     const plan::Tile& t = st.tiles[0];
     const int32_t* const lp = st.lvlptr.data() + t.lvl_off;

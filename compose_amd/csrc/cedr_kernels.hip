@@ -3130,40 +3130,38 @@ inline int chunk_split (int ntiles, int nchunks, int target, bool round_down = f
 // The tail split of a first-stage launch (work_item): with 'wgs' resident workgroups per XCD (occupancy x 32 CUs), the
 // tiles of an XCD's range that lie past its last full round go to k workgroups each. Only for stages of at least two
 // full rounds whose chunks are not split already; CEDR_HIP_TAIL = k (default 5; 0 or 1 = off), CEDR_HIP_TAIL_ROUNDS = r
-// (default 0): r more full rounds are split as well.
+// (default 0): r more full rounds are split as well. A full round is sized for a kernel that has the whole device; on a
+// CU-masked stream, or next to another stream's kernels, the split can fall mid-round (performance only, not results).
 template <typename K>
-TailSplit tail_split (K kernel, const size_t lds, const int ntiles, const int nchunks, const int ysplit) {
-  // (read at every launch, not once: the parity test switches them inside one process)
-  const char* const kv = std::getenv("CEDR_HIP_TAIL");
-  const char* const rv = std::getenv("CEDR_HIP_TAIL_ROUNDS");
-  const int k_env = kv ? std::atoi(kv) : kTailK, r_env = rv ? std::atoi(rv) : 0;
+TailSplit tail_split (K kernel, const size_t lds, const cedr_hip_stage* st, const int nchunks, const int ysplit) {
+  // The knobs travel with the stage (DeviceStage::upload reads the environment once, bits 16-31 of flags): no getenv
+  // on the launch path, which run() takes on every step and which ranks-as-threads tests take concurrently.
+  const int ntiles = st->ntiles;
+  const int k_env = (st->flags & CEDR_STAGE_TAIL_SET) ? ((st->flags >> 16) & 0x7f) : kTailK;
+  const int r_env = (st->flags >> 24) & 0x7f;
   TailSplit t{0, 1};
   if (k_env < 2 || ysplit != 1 || nchunks < 2) return t;
-  // (resident workgroups per XCD for this kernel and LDS size: asked once, the answer is kept -- the query is not
-  // free and run() launches this on every step; a handful of (kernel, lds) pairs per process)
+  // (resident workgroups per XCD for this kernel and LDS size: asked once per thread, the answer is kept -- the query
+  // is not free; a handful of (kernel, lds) pairs per process. Thread-local: no lock on the launch path.)
   struct Known { const void* k; size_t lds; int dev, wgs; };
-  static std::vector<Known> known;
-  static std::mutex mtx;
+  static thread_local std::vector<Known> known;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) { (void) hipGetLastError(); return t; }
   int wgs = -1;
-  {
-    std::lock_guard<std::mutex> lock(mtx);
-    for (const Known& kn : known)
-      if (kn.k == reinterpret_cast<const void*>(kernel) && kn.lds == lds && kn.dev == dev) wgs = kn.wgs;
-    if (wgs < 0) {
-      int occ = 0, ncu = 0;
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, kBlock, lds) != hipSuccess || occ < 1 ||
-          hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu < 8) {
-        (void) hipGetLastError();
-        wgs = 0;
-      } else {
-        wgs = occ*(ncu/8);
-      }
-      if (std::getenv("CEDR_HIP_TAIL_VERBOSE"))
-        std::fprintf(stderr, "cedr: tail split: %d workgroups per CU, %d CUs, lds %zu\n", occ, ncu, lds);
-      known.push_back(Known{reinterpret_cast<const void*>(kernel), lds, dev, wgs});
+  for (const Known& kn : known)
+    if (kn.k == reinterpret_cast<const void*>(kernel) && kn.lds == lds && kn.dev == dev) wgs = kn.wgs;
+  if (wgs < 0) {
+    int occ = 0, ncu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, kBlock, lds) != hipSuccess || occ < 1 ||
+        hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu < 8) {
+      (void) hipGetLastError();
+      wgs = 0;
+    } else {
+      wgs = occ*(ncu/8);
     }
+    static const bool verbose = std::getenv("CEDR_HIP_TAIL_VERBOSE") != nullptr;
+    if (verbose) std::fprintf(stderr, "cedr: tail split: %d workgroups per CU, %d CUs, lds %zu\n", occ, ncu, lds);
+    known.push_back(Known{reinterpret_cast<const void*>(kernel), lds, dev, wgs});
   }
   if (wgs < 1) return t;
   const int per = (ntiles + 7)/8;
@@ -3229,7 +3227,7 @@ int cedr_hip_tree_up_rows_sums (const cedr_hip_stage* st, int32_t nfields, const
     auto go = [&] (auto kernel) -> int {
       int e = set_lds_limit(kernel, lds);
       if (e) return e;
-      const TailSplit tail = tail_split(kernel, lds, st->ntiles, (nfields + FTr - 1)/FTr, gridx.y);
+      const TailSplit tail = tail_split(kernel, lds, st, (nfields + FTr - 1)/FTr, gridx.y);
       hipLaunchKernelGGL(kernel, dim3(xcd_grid_tail(st->ntiles, tail), gridx.y), dim3(kBlock), lds, stream,
                          *st, nfields, op, stride, data, in_rows, nrow, zero_init, pitch, tail);
       return 0;
@@ -3311,7 +3309,7 @@ int cedr_hip_qlt_down_rows (const cedr_hip_qlt_layout* lay, const cedr_hip_stage
       auto gosp = [&] (auto kernel) -> int {
         int e2 = set_lds_limit(kernel, ldss);
         if (e2) return e2;
-        const TailSplit tail = tail_split(kernel, ldss, st->ntiles, (nt + TTm - 1)/TTm, gridm.y);
+        const TailSplit tail = tail_split(kernel, ldss, st, (nt + TTm - 1)/TTm, gridm.y);
         hipLaunchKernelGGL(kernel, dim3(xcd_grid_tail(st->ntiles, tail), gridm.y), dim3(kBlock), ldss, stream,
                            *lay, *st, l2r, r2l, in_rows, out_rows, nrow, pitchs, tail);
         return 0;

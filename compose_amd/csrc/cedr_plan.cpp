@@ -2,6 +2,7 @@
 #include "cedr_plan.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 
 #include "cedr_util.hpp"
@@ -433,6 +434,12 @@ Plan build (const tree::FlatTree& t, int32_t my_rank, int32_t nranks,
                 "it there needs point-to-point messages per tree level, which this communicator does not have "
                 "(mpi::Comm::has_exchange): override has_exchange() / exchange(), or drop the pin");
   if (pinned_inside && opt.exchange == 0 && nranks > 1) return build_level_mode(t, my_rank, nranks, leaf_slot, opt);
+  // exchange == 1 (the caller insists on the all-gather design) cannot honour such a pin either: the node would be
+  // computed by the owner of the cells below it. Refused like the case above, not done silently (cedr_mpi.hpp).
+  cedr_throw_if(pinned_inside && opt.exchange == 1 && nranks > 1,
+                "tree::Node::rank pins a node to another rank than the one owning every cell below it, and exchange = 1 "
+                "(CEDR_HIP_EXCHANGE=1: one all-gather + replicated top) computes every node where its cells are: drop "
+                "the pin, or leave exchange at 0 / 2 so that the plan exchanges tree levels point to point");
 
   // Boundary roots = roots of maximal single-rank subtrees, in DFS order.
   std::vector<int32_t> broots;
@@ -457,9 +464,8 @@ Plan build (const tree::FlatTree& t, int32_t my_rank, int32_t nranks,
     const int64_t nb_max = *std::max_element(per_rank.begin(), per_rank.end());
     if (nranks*nb_max > 16384 + 2*ncells/nranks) {
       if ( ! opt.no_p2p) return build_level_mode(t, my_rank, nranks, leaf_slot, opt);
-      static bool warned = false;
-      if ( ! warned && my_rank == 0) {
-        warned = true;
+      static std::atomic<bool> warned(false);  // (ranks may be threads of one process)
+      if (my_rank == 0 && ! warned.exchange(true)) {
         std::fprintf(stderr, "cedr (hip): ownership is scattered (%lld boundary subtrees per rank at most, %lld cells "
                      "on %d ranks) and the communicator has no point-to-point exchange (mpi::Comm::has_exchange): "
                      "falling back to one all-gather of %lld records; every rank then holds and sweeps about the "

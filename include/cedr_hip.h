@@ -62,6 +62,10 @@ enum { CEDR_STAGE_UNIFORM64 = 1,
 /* fused top tile: the first level's node j has the inputs 2j and 2j + 1 as its kids and there are nleaf/2 of
  * them, so its loads need not wait for the kid table */
        CEDR_STAGE_LVL0_PAIRS = 2 };
+/* bits 16..31 of flags: launch-shape knobs read from the environment when the stage is put on the device (so that no
+ * launch reads the environment): CEDR_STAGE_TAIL_SET says bits 16..22 hold CEDR_HIP_TAIL (workgroups per tail tile;
+ * unset = the built-in default), bits 24..30 CEDR_HIP_TAIL_ROUNDS */
+enum { CEDR_STAGE_TAIL_SET = 1 << 23 };
 /* fused top tile, bits 8..15 of flags: 1 + the first level of the NARROW suffix of the tile's levels (every
  * level from there up has at most 64 nodes; one wave walks those without workgroup barriers); 0 = not given */
 

@@ -339,6 +339,23 @@ int main () {
         }
     }
   check_node_built_partial_trees();
+  {  // util::IdMap's contract (the engine's gci2lci and the C ABI's g2l rely on it), dense and sparse form:
+     // a duplicate id returns its FIRST index, size() is the number of adds, an absent id gives -1
+    for (const int stride : {1, 100000}) {  // ids 0, s, 2s, ...: one block -> direct table; far apart -> sorted pairs
+      util::IdMap m;
+      const int ids[] = {5, 2, 9, 2, 7, 5};
+      for (int i = 0; i < 6; ++i) m.add(ids[i]*stride, 10 + i);
+      m.finish();
+      bool ok = m.size() == 6 && m.find(2*stride) == 11 && m.find(5*stride) == 10 && m.find(9*stride) == 12 &&
+        m.find(7*stride) == 14 && m.find(3*stride) == -1 && m.find(-1) == -1 && m.find(10*stride) == -1 &&
+        m.find(2*stride + 1) == -1;
+      util::IdMap e;
+      e.finish();
+      ok = ok && e.size() == 0 && e.find(0) == -1;
+      if ( ! ok) { std::printf("IdMap contract broken (stride %d)\n", stride); ++g_fail; }
+      ++ncase;
+    }
+  }
   std::printf("%ld plans checked, %d failures\n", ncase, g_fail);
   std::printf(g_fail ? "FAIL\n" : "PASS\n");
   return g_fail ? 1 : 0;

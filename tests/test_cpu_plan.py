@@ -376,7 +376,7 @@ def test_plan_invariants_under_sanitizers():
     assert res.returncode == 0 and "PASS" in res.stdout, res.stdout[-2000:] + res.stderr[-3000:]
 
 
-def test_transport_without_point_to_point_refuses_what_it_would_drop(ca, capfd):
+def test_transport_without_point_to_point_refuses_what_it_would_drop(ca, capfd, monkeypatch):
     """mpi::Comm::has_exchange() false (two-callback transport): a tree::Node::rank pin that only level mode
     honours is an error at construction (it used to be dropped silently); scattered ownership of a full tree
     still plans for the all-gather, with a warning on rank 0's stderr."""
@@ -392,6 +392,13 @@ def test_transport_without_point_to_point_refuses_what_it_would_drop(ca, capfd):
         if pinned:
             with pytest.raises(ca.CedrError, match="pins a node"):
                 ca.QLT(ca.Parallel.callbacks(0, 2, bad, bad), 4, tree())
+            # ... and so is insisting on the all-gather design (exchange = 1), which would compute the node where
+            # its cells are: refused, with or without point-to-point messages
+            monkeypatch.setenv("CEDR_HIP_EXCHANGE", "1")
+            for par in (ca.Parallel.callbacks(0, 2, bad, bad), ca.Parallel.callbacks_p2p(0, 2, bad, bad, bad)):
+                with pytest.raises(ca.CedrError, match="pins a node"):
+                    ca.QLT(par, 4, tree())
+            monkeypatch.delenv("CEDR_HIP_EXCHANGE")
         else:
             ca.QLT(ca.Parallel.callbacks(0, 2, bad, bad), 4, tree())
     nc = 40000  # pseudorandom ownership: level mode by the planner's own rule

@@ -306,3 +306,26 @@ def test_top_tile_follows_the_lds_the_device_grants(gpu, oracle, limit, max_top_
         if limit:
             assert 72 * (nin - 1) + 10 * 1024 <= int(limit)
     assert np.array_equal(common.run_hip_qlt(ca, q, v), want)
+
+
+def test_device_lds_does_not_cap_the_top_tile(gpu, monkeypatch):
+    """engine::plan_options bounds the fused top tile by the LDS the device grants a workgroup. An MI355X grants
+    160 KB: the plan a QLT runs (made with the device in view) must be the plan made on the host alone
+    (cedr_plan_create never touches a GPU, so nothing caps it) -- at a size whose top tile takes the full 2048 inputs.
+    A runtime that reported less would shrink the tile silently otherwise (the library now also says so on stderr)."""
+    ca = gpu
+    for k in ("CEDR_HIP_TOP_MAX", "CEDR_HIP_LDS_LIMIT", "CEDR_HIP_TOP", "CEDR_HIP_MICRO", "CEDR_HIP_MICRO_CUT",
+              "CEDR_HIP_MICRO_CUT2", "CEDR_HIP_TILE_LEAVES", "CEDR_HIP_EXCHANGE"):
+        monkeypatch.delenv(k, raising=False)
+    n = 1500000
+    tree = ca.Tree.make_1d(n)
+    q = ca.QLT(ca.Parallel.self_(), n, tree)
+    q.declare_tracer(7, 0)
+    q.end_tracer_declarations()
+    dev_plan = q.plan()
+    hp = ca.lib().cedr_plan_create(tree.h, n, 0, 1, 0)
+    host_plan = ca.dump_plan(hp, 1)
+    ca.lib().cedr_plan_free(hp)
+    shape = lambda p: [(len(st["tiles"]), bool(st["top"]), int(st["tiles"][0][1])) for st in p["local"]]
+    assert shape(dev_plan) == shape(host_plan)
+    assert dev_plan["local"][-1]["top"] and int(dev_plan["local"][-1]["tiles"][0][1]) == 2048

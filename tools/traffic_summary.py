@@ -14,7 +14,10 @@ ncells, nt = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (150
 # rocprof kernel name -> the name bench.py's launch profiler uses, first stage only (largest grid)
 OURS = {"qlt_down_micro_kernel": "qlt_down_kernel", "qlt_down_sp_kernel": "qlt_down_kernel",
         "tree_up_micro_kernel": "tree_up_kernel",
-        "caas_reduce_kernel": "caas_reduce_kernel", "caas_finish_kernel": "caas_finish_kernel"}
+        "caas_reduce_kernel": "caas_reduce_kernel", "caas_finish_kernel": "caas_finish_kernel",
+        # CAAS fused with the BFB reducer's first stage (bench.py --caas-bfb N): group sums in registers / in LDS
+        "caas_reduce_bfb_p2_kernel": "caas_reduce_bfb_kernel", "caas_reduce_bfb_kernel": "caas_reduce_bfb_kernel",
+        "caas_reduce_accum_lds_kernel": "caas_reduce_accum_kernel"}
 raw = {}
 for tag in ("FETCH_SIZE", "WRITE_SIZE", "odd_FETCH_SIZE", "odd_WRITE_SIZE"):
     agg = collections.defaultdict(list)
@@ -43,5 +46,8 @@ json.dump({
                 "here on a known byte count: caas_reduce_kernel reads ncells*ntracers*32 B per launch, and its "
                 "FETCH_SIZE is half of that with 16-byte accesses and (odd cell count, see calibration) with 8-byte "
                 "accesses alike -- so hbm_bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024. WRITE_SIZE is exact.",
+    # sha256 of the cedr_kernels.hip the profiled library was built from (KSHA, set by tools/final_profiles.sh from
+    # compose_amd.kernels_sha256()): bench.py refuses this file for a library built from other kernel code
+    "kernels_sha256": __import__("os").environ.get("KSHA"),
     "config": {"ncells": ncells, "ntracers": nt}, "kernels": kernels, "calibration_odd_cell_count": cal},
     open(d + "/r_traffic.json", "w"), indent=1)
