@@ -122,6 +122,10 @@ void QLTHip::init (const Parallel::Ptr& p, const Int& ncells, const tree::FlatTr
   plan::Options popt;
   engine::plan_options(popt);  // the environment's knobs; the fused top tile bounded by the device's LDS
   eng_.reset(new engine::TreeEngine(p, tree, *ns_, popt));
+  // How deep the tiles are cut pays or not by the tracer list (end_tracer_declarations), which is not known yet:
+  // the tree is kept until then unless the environment fixes the cuts.
+  if ( ! std::getenv("CEDR_HIP_MICRO_CUT") && ! std::getenv("CEDR_HIP_MICRO_CUT2") && popt.micro && popt.fused_top)
+    tree_keep_.reset(new tree::FlatTree(tree));
   mdb_.reset(new std::vector<int>());
   d_.reset(new Impl());
   o.l2r_data = o.r2l_data = nullptr;
@@ -176,6 +180,24 @@ void QLTHip::end_tracer_declarations () {
   cedr_throw_if( ! mdb_, "end_tracer_declarations was already called.");
   md_.init(*mdb_);
   mdb_.reset();
+  // The planner's default cuts (first stage 3 LDS levels, later stages 4) trade one more dependent level per chunk of
+  // the first-stage root->leaves sweep -- a cost per tracer -- for smaller, fewer small stages -- a saving per run
+  // (profiles/r05_experiments.md 3: QLT::run -1 to -2 % at 40 shape-preserving tracers, but +3 % at 128, and +6 % of the
+  // first stage for mixed types, whose general kernel walks a level more slowly). Many tracers, or any tracer that is
+  // not shape preserving: round 4's cuts (2 / 3). One more plan build, here, for those lists only.
+  if (tree_keep_) {
+    bool all_sp = true;
+    for (const int pt : md_.trcr2prob) if ( ! (pt & ProblemType::shapepreserve)) all_sp = false;
+    if ( ! all_sp || md_.trcr2prob.size() > 64) {
+      plan::Options popt;
+      engine::plan_options(popt);
+      popt.micro_cut = 2;
+      popt.micro_cut2 = 3;
+      eng_.reset(new engine::TreeEngine(p_, *tree_keep_, *ns_, popt));
+      o.stride = eng_->stride();
+    }
+    tree_keep_.reset();
+  }
 }
 
 // Sizes in Reals. The reference returns ndps * nslots (cedr_qlt.cpp:293-298);

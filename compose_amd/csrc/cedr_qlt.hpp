@@ -131,6 +131,7 @@ private:
   Parallel::Ptr p_;
   std::shared_ptr<const tree::NodeSets> ns_;
   std::unique_ptr<engine::TreeEngine> eng_;
+  std::unique_ptr<tree::FlatTree> tree_keep_;  // the caller's tree, until end_tracer_declarations has chosen the plan's cuts
   util::IdMap gci2lci_;
   std::unique_ptr<std::vector<int> > mdb_;  // tracer declarations in progress
   MetaData md_;

@@ -408,3 +408,27 @@ def test_transport_without_point_to_point_refuses_what_it_would_drop(ca, capfd, 
     q.end_tracer_declarations()
     assert not q.plan()["level_mode"]
     assert "falling back to one all-gather" in capfd.readouterr().err
+
+
+def test_cuts_follow_the_tracer_list(ca, monkeypatch):
+    """The plan's cuts are chosen when the tracer list is known (QLT::end_tracer_declarations): up to 64 tracers, all shape
+    preserving: first-stage tiles keep three LDS levels, later ones four; many tracers or any other problem type: two and
+    three (round 4's). The environment's CEDR_HIP_MICRO_CUT / CUT2 override the rule."""
+    for k in ("CEDR_HIP_MICRO_CUT", "CEDR_HIP_MICRO_CUT2", "CEDR_HIP_MICRO", "CEDR_HIP_TOP", "CEDR_HIP_TILE_LEAVES"):
+        monkeypatch.delenv(k, raising=False)
+    n = 200000
+
+    def first_stage_levels(types):
+        q = ca.QLT(ca.Parallel.self_(), n, ca.Tree.make_1d(n))
+        for t in types:
+            q.declare_tracer(t, 0)
+        q.end_tracer_declarations()
+        st = q.plan()["local"]
+        return max(int(t[6]) for t in st[0]["tiles"]), [len(s["tiles"]) for s in st]
+    assert first_stage_levels([7] * 40)[0] == 3
+    assert first_stage_levels([7, 3, 2] * 10)[0] == 3       # cst, cs, s: all shape preserving
+    assert first_stage_levels([7] * 65)[0] == 2             # many tracers
+    assert first_stage_levels([7] * 39 + [4])[0] == 2       # a t-only tracer among them
+    assert first_stage_levels([9])[0] == 2                  # nonnegative
+    monkeypatch.setenv("CEDR_HIP_MICRO_CUT", "3")
+    assert first_stage_levels([7] * 65)[0] == 3             # the environment decides

@@ -69,23 +69,24 @@ def test_caas_user_reducer(gpu, oracle, ncells, accum):
 # where a tile's cells fit); 3 and 1: odd groups (8-byte loads, LDS form); 6, 10: LDS form, 10 with more than 1024 cells
 # per tile (loop form); 44, 64: too many cells for a tile's LDS -> not fused; 1500 groups: one stage of micro tiles
 # under the top tile; 40 groups: a single tile.
-@pytest.mark.parametrize("ngroups,accum,expect_fused", [
-    (5000, 4, True), (5000, 3, True), (3000, 1, True), (4097, 2, True), (2500, 10, True), (40000, 4, True),
-    (2304, 44, False), (1500, 4, True), (40, 4, None), (12345, 6, True), (3000, 16, True), (2001, 8, True),
-    (1500, 32, True), (700, 64, False)])
+_BFB_CASES = [(5000, 4, True), (5000, 3, True), (3000, 1, True), (4097, 2, True), (2500, 10, True), (40000, 4, True),
+              (2304, 44, False), (1500, 4, True), (40, 4, None), (12345, 6, True), (3000, 16, True), (2001, 8, True),
+              (1500, 32, True), (700, 64, False)]
+
+
+@pytest.mark.parametrize("ngroups,accum,expect_fused,park",
+                         [c + (False,) for c in _BFB_CASES] +
+                         # park: the LDS form of the fused kernel also for the group sizes that are otherwise summed in
+                         # registers (with 16 and more cells per group a tile's cells rarely fit the LDS: fused or not)
+                         [(g, a, e if a < 16 else None, True) for g, a, e in _BFB_CASES if a in (2, 4, 8, 16, 32)])
 @pytest.mark.parametrize("imbalanced", [False, True])
-@pytest.mark.parametrize("park", [False, True])
 def test_caas_bfb_pairing_fused_bitwise(gpu, oracle, monkeypatch, ngroups, accum, expect_fused, imbalanced, park):
     """CAAS whose UserAllReducer is the BFB tree reducer (cedr_caas.cpp:137-168,263-266 +
     cedr_bfb_tree_allreduce.cpp:79-159): the fused kernel (typed pairing) gives the bits of the two separate
     launches (callback pairing) and of the restatement with the oracle's tree sum."""
     ca = gpu
-    if park:  # the LDS form of the fused kernel also for the group sizes that are otherwise summed in registers
-        if accum not in (2, 4, 8, 16, 32):
-            pytest.skip("no register form for this group size anyway")
+    if park:
         monkeypatch.setenv("CEDR_HIP_CAAS_BFB_P2", "0")
-        if accum >= 16:
-            expect_fused = None  # (too many cells per tile for the LDS form, unless the tree's tiles are small)
     trs = R.caas_tracers(R.tracers_vector())
     types = [t.problem_type for t in trs]
     v = R.make_values(trs, ngroups * accum, seed=ngroups + accum)
