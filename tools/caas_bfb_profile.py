@@ -65,8 +65,8 @@ for typed in (True, False):
     for acc in accs1:
         res.append(run("1 GPU, 1.5M cells, %d cells per leaf" % acc, ca.Parallel.self_, N, 1, acc, typed))
     for acc in accs8:
-        res.append(run("rank 0 of 8 (stub transport), 187.5k cells, %d cells per leaf" % acc,
-                       lambda: ca.Parallel.callbacks(0, P, ag, ar), N, P, acc, typed))
+        res.append(run("rank 0 of 8 (rehearsal communicator), 187.5k cells, %d cells per leaf" % acc,
+                       lambda: ca.Parallel.rehearsal(ca.Parallel.self_(), P), N, P, acc, typed))
 # the own-reducer CAAS beside it
 def own(label, n):
     caas = ca.CAAS(ca.Parallel.self_(), n)

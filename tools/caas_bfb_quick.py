@@ -40,7 +40,7 @@ def run(par, world):
     for name, aux, m in ca.profile_stop(): ks.setdefault(name, []).append(m)
     return best, caas.fused_with_bfb(), {k: sum(v)/20 for k, v in ks.items()}
 knobs = " ".join("%s=%s" % kv for kv in sorted(os.environ.items()) if kv[0].startswith("CEDR_HIP_"))
-for label, par, world in (("1.5M", ca.Parallel.self_(), 1), ("rank0of8", ca.Parallel.callbacks(0, P, ag, ar), P)):
+for label, par, world in (("1.5M", ca.Parallel.self_(), 1), ("rank0of8", ca.Parallel.rehearsal(ca.Parallel.self_(), P), P)):
     ms, fused, ks = run(par, world)
     print("%-28s acc %d %-9s fused=%d CAAS::run %.4f ms | %s" % (knobs, acc, label, fused, ms,
           " ".join("%s %.4f" % (k.replace("_kernel", ""), v) for k, v in sorted(ks.items(), key=lambda kv: -kv[1]))), flush=True)

@@ -57,4 +57,4 @@ def ar(s, r, cnt, st):
     if s != r: L.cedr_memcpy_d2d_async(r, s, 8*cnt, st)
     return 0
 report("config B (150k cells x 10 tracers, one rank)", ca.Parallel.self_(), 150000, 1, 10)
-report("187.5k-cell shard x 40 tracers as rank 0 of 8 (stub transport)", ca.Parallel.callbacks(0, P, ag, ar), 1500000, P, 40)
+report("187.5k-cell shard x 40 tracers as rank 0 of 8 (rehearsal communicator)", ca.Parallel.rehearsal(ca.Parallel.self_(), P), 1500000, P, 40)

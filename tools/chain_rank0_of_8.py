@@ -28,7 +28,7 @@ def xch(ops, st):   # one round of point-to-point messages: receives are stream-
         if not is_send: L.cedr_memcpy_d2d_async(ptr, fake.data_ptr(), 8*cnt, st)
     return 0
 qa = mk(ca.Parallel.self_(), n//P, 1)
-qb = mk(ca.Parallel.callbacks(0, P, ag, ar), n, P)
+qb = mk(ca.Parallel.rehearsal(ca.Parallel.self_(), P), n, P)  # rank 0 of 8: collectives = stream-ordered device copies, no Python in the loop
 qc = mk(ca.Parallel.callbacks_p2p(0, P, ag, ar, xch), n, P, prune=0)
 assert qc.plan()["level_mode"]
 for q in (qa, qb, qc):
