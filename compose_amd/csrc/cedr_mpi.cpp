@@ -16,13 +16,16 @@ namespace mpi {
 namespace {
 
 // RehearsalComm: blocks 1 .. P-1 of an all-gather's result = copies of block 0, in ONE launch (P - 1 separate
-// hipMemcpyAsync calls cost a rehearsed step ~1.5 us each, which no real all-gather would).
+// hipMemcpyAsync calls cost a rehearsed step ~1.5 us each, which no real all-gather would). Host-only builds of this
+// file (tests/cpp/plan_check.cpp under g++ with sanitizers) have no kernels: they take the copies.
+#ifdef __HIPCC__
 __global__ void rehearsal_replicate_kernel (Real* __restrict__ recv, const size_t count, const int nblocks) {
   const size_t i = static_cast<size_t>(blockIdx.x)*blockDim.x + threadIdx.x;
   if (i >= count) return;
   const Real v = recv[i];
   for (int r = 1; r < nblocks; ++r) recv[static_cast<size_t>(r)*count + i] = v;
 }
+#endif
 
 // ------------------------------------------------------------------ single rank
 struct SelfComm : public Comm {
@@ -205,9 +208,18 @@ struct RehearsalComm : public Comm {
   int allgather (const Real* send, Real* recv, size_t count, hipStream_t s) override {
     const int e = inner_->allgather(send, recv, count, s);  // block 0, through the real communicator
     if (e || size_ == 1 || count == 0) return e;
+#ifdef __HIPCC__
     hipLaunchKernelGGL(rehearsal_replicate_kernel, dim3(static_cast<unsigned>((count + 255)/256)), dim3(256), 0, s,
                        recv, count, size_);
     return static_cast<int>(hipGetLastError());
+#else
+    for (int r = 1; r < size_; ++r) {
+      const hipError_t h = hipMemcpyAsync(recv + static_cast<size_t>(r)*count, recv, count*sizeof(Real),
+                                          hipMemcpyDeviceToDevice, s);
+      if (h != hipSuccess) return static_cast<int>(h);
+    }
+    return 0;
+#endif
   }
   int allreduce_sum (const Real* send, Real* recv, size_t count, hipStream_t s) override {
     return inner_->allreduce_sum(send, recv, count, s);

@@ -117,6 +117,14 @@ def caas_exact_sums(v, tracers):
     return out
 
 
+def default_knobs():
+    """True unless the environment switches some code path of the library (the env matrix of tools/env_matrix.sh runs the
+    suites under such settings): then results must still be right, but which path produced them -- fused or not, how a plan
+    is shaped -- is not asserted."""
+    import os
+    return not any(k.startswith("CEDR_HIP_") and k not in ("CEDR_HIP_PLACE_TRIES", "CEDR_HIP_LIB") for k in os.environ)
+
+
 def caas_bfb_expected(oracle, v, types, ngroups, accum, imbalanced=False):
     """CAAS paired with the BFB tree reducer over groups of `accum` cells, restated from the reference with the
     ORACLE's tree sum in the middle: clip and per-group partial sums 0 + c0 + c1 + ... (cedr_caas.cpp:140-168),

@@ -85,6 +85,8 @@ def test_caas_bfb_pairing_fused_bitwise(gpu, oracle, monkeypatch, ngroups, accum
     cedr_bfb_tree_allreduce.cpp:79-159): the fused kernel (typed pairing) gives the bits of the two separate
     launches (callback pairing) and of the restatement with the oracle's tree sum."""
     ca = gpu
+    if not common.default_knobs():
+        expect_fused = None  # (env matrix: another code path may be forced; the bits must hold anyway)
     if park:
         monkeypatch.setenv("CEDR_HIP_CAAS_BFB_P2", "0")
     trs = R.caas_tracers(R.tracers_vector())
@@ -110,9 +112,10 @@ def test_caas_bfb_pairing_fuse_knob_and_reruns(gpu, oracle, monkeypatch):
     ngroups, accum = 6000, 4
     v = R.make_values(trs, ngroups * accum, seed=11)
     want = common.caas_bfb_expected(oracle, v, types, ngroups, accum)
+    dflt = common.default_knobs()
     for kw in (dict(nrepeat=3), dict(qm_source=True)):
         got, fused = common.run_hip_caas_bfb(ca, ngroups, accum, types, v, typed=True, **kw)
-        assert fused and np.array_equal(got, want)
+        assert (fused or not dflt) and np.array_equal(got, want)
     monkeypatch.setenv("CEDR_HIP_CAAS_BFB_FUSE", "0")
     got, fused = common.run_hip_caas_bfb(ca, ngroups, accum, types, v, typed=True)
     assert not fused and np.array_equal(got, want)

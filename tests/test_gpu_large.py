@@ -238,7 +238,7 @@ def test_config_C_sharded_8_ways(gpu, oracle):
             # the reducer object itself as the UserAllReducer (caas::BfbUserAllReducer): run() fuses the reduce pass
             # with the first stage of the reducer's tree
             cb = declare(ca.CAAS(par, len(g), bfb, acc))
-            assert cb.fused_with_bfb()
+            assert cb.fused_with_bfb() or not common.default_knobs()
             cb.set_rhom(loc[0]); cb.set_Qm(loc[1], loc[2], loc[3], loc[4]); cb.run()
             cb.get_Qm(o); ca.synchronize()
             outs[2][:, g] = o

@@ -1,8 +1,8 @@
 #!/bin/bash
-# The randomised soaks in one call (bit-for-bit against the oracle). Writes gpurun_out/${RN:-r04}soak/summary.txt.
+# The randomised soaks in one call (bit-for-bit against the oracle). Writes gpurun_out/${RN:-r05}soak/summary.txt.
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd "$R"
-O=gpurun_out/${RN:-r04}soak
+O=gpurun_out/${RN:-r05}soak
 mkdir -p $O
 echo "# Soaks on one MI355X at HEAD $(cat .head_sha 2>/dev/null | tr '\n' ' ') (bit-for-bit against the oracle)" > $O/summary.txt
 run () {  # name, count
