@@ -591,11 +591,13 @@ def main():
                                 "%s splits the same trace by kernel instantiation "
                                 "and launch grid (tools/kernel_stats_by_grid.py)" % by_grid)
         if dom["kernel"] == "qlt_down_kernel":
-            roofline["bound_note"] = ("reported against the HBM roofline, the metric's roofline. Without any node problem the "
-                                      "kernel takes 0.36 ms: what the memory system delivers to its access pattern (three read "
-                                      "rows and one written row per tracer in 1.4 KB pieces 12 MB apart) at five workgroups per "
-                                      "CU; neither a prefetch of the next chunk by LDS-DMA nor a cheaper per-tile setup moves "
-                                      "that, one wave per SIMD less costs 10 %, and the node problems add 0.03-0.04 ms "
+            roofline["bound_note"] = ("reported against the HBM roofline, the metric's roofline. Since round 5 the first-stage tiles of a "
+                                      "list of up to 64 shape-preserving tracers keep THREE LDS levels: this launch walks one more "
+                                      "dependent level per chunk (0.39 -> 0.43 ms, 61 -> 56 % of 8 TB/s) and QLT::run as a whole gets "
+                                      "faster (half the output lines of the leaves->root launch, half the second stage, no third: "
+                                      "qlt.frac; profiles/r05_experiments.md 3). With two levels and no node problems the kernel takes "
+                                      "0.36 ms: what the memory system delivers to its access pattern (three read rows and one "
+                                      "written row per tracer in 1.4 KB pieces 12 MB apart) at five workgroups per CU "
                                       "(profiles/r04_experiments.md 1, 5)")
         elif dom["kernel"] == "tree_up_kernel":
             roofline["bound_note"] = ("the reads stream at the copy rate (0.317 ms without the output stores); the gap is the 1.3 M "

@@ -8,7 +8,9 @@
 //   cedr_test_hip [-nc ncells] [--imbalanced] [--prefer-mass-con]
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
+#include <memory>
 #include <cstdint>
 #include <cstdio>
 #include <string>
@@ -18,6 +20,7 @@
 #include <type_traits>
 #include <vector>
 
+#include "cedr_bfb_tree_allreduce.hpp"
 #include "cedr_caas.hpp"
 #include "cedr_qlt.hpp"
 
@@ -257,6 +260,64 @@ static int drive (const char* name, CDRT& cdr, const std::vector<Tracer>& ts, in
   return nerr;
 }
 
+// THE PRODUCTION PAIRING from C++: CAAS whose UserAllReducer hands its per-group partial sums to a BfbTreeAllReducer.
+// (a) as a host model writes it around the reference (cedr_caas.hpp:27-49): its own UserAllReducer subclass calling
+// allreduce(send, recv, /*transpose*/ true); (b) with this build's caas::BfbUserAllReducer, which a CAAS fuses with the
+// first stage of the reducer's tree. Same inputs through the DeviceOp kernels: the masses must agree bit for bit and pass
+// the harness's checks.
+struct HandWrittenReducer : public cedr::caas::CAAS<>::UserAllReducer {
+  std::shared_ptr<cedr::BfbTreeAllReducer<> > bfb; int nacc;
+  HandWrittenReducer (const std::shared_ptr<cedr::BfbTreeAllReducer<> >& b, int n) : bfb(b), nacc(n) {}
+  int operator() (const cedr::mpi::Parallel&, Real* sendbuf, Real* rcvbuf, int, int, MPI_Op) const override {
+    bfb->allreduce(sendbuf, rcvbuf, true);
+    return 0;
+  }
+  int n_accum_in_place () const override { return nacc; }
+};
+
+static int pairing (const cedr::mpi::Parallel::Ptr& p, const std::vector<Tracer>& ts, const int ngroups, const int nacc) {
+  const int n = ngroups*nacc, nt = (int) ts.size();
+  Values v(n, nt);
+  generate(ts, v);
+  const size_t N = (size_t) n*nt*sizeof(Real);
+  Real* d[6];
+  HIP_OK(hipMalloc((void**) &d[0], n*sizeof(Real)));
+  for (int k = 1; k < 6; ++k) HIP_OK(hipMalloc((void**) &d[k], N));
+  HIP_OK(hipMemcpy(d[0], v.rhom.data(), n*sizeof(Real), hipMemcpyHostToDevice));
+  const Real* src[] = {v.Qm.data(), v.lo.data(), v.hi.data(), v.prev.data()};
+  for (int k = 0; k < 4; ++k) HIP_OK(hipMemcpy(d[k+1], src[k], N, hipMemcpyHostToDevice));
+  std::vector<Real> out[2];
+  bool fused[2] = {false, false};
+  for (int form = 0; form < 2; ++form) {
+    auto bfb = std::make_shared<cedr::BfbTreeAllReducer<> >(p, cedr::tree::make_tree_over_1d_mesh(p, ngroups), ngroups, 4*nt);
+    cedr::caas::CAAS<>::UserAllReducer::Ptr red;
+    if (form == 0) red = std::make_shared<HandWrittenReducer>(bfb, nacc);
+    else red = std::make_shared<cedr::caas::BfbUserAllReducer>(bfb, nacc);
+    cedr::caas::CAAS<> caas(p, n, red);
+    for (const auto& t : ts) caas.declare_tracer(t.pt, 0);
+    caas.end_tracer_declarations();
+    caas.finish_setup();
+    fused[form] = caas.fused_with_bfb_reducer();
+    const auto op = caas.get_device_op();
+    const int B = 256;
+    k_set_rhom<<<(n + B - 1)/B, B>>>(op, n, d[0]);
+    k_set_Qm<<<(n*nt + B - 1)/B, B>>>(op, n, nt, d[1], d[2], d[3], d[4]);
+    caas.run();
+    k_get_Qm<<<(n*nt + B - 1)/B, B>>>(op, n, nt, d[5]);
+    HIP_OK(hipDeviceSynchronize());
+    out[form].resize((size_t) n*nt);
+    HIP_OK(hipMemcpy(out[form].data(), d[5], N, hipMemcpyDeviceToHost));
+  }
+  for (int k = 0; k < 6; ++k) (void) hipFree(d[k]);
+  int nerr = 0;
+  if (fused[0]) { std::printf("FAIL pairing: a foreign UserAllReducer must not be fused\n"); ++nerr; }
+  size_t nd = 0;
+  for (size_t i = 0; i < out[0].size(); ++i) if (std::memcmp(&out[0][i], &out[1][i], sizeof(Real))) ++nd;
+  if (nd) { std::printf("FAIL pairing: caas::BfbUserAllReducer (fused: %d) differs from the hand-written reducer in %zu values\n",
+                        (int) fused[1], nd); ++nerr; }
+  return nerr + check("CAAS+BFB", ts, v, out[1], false);
+}
+
 int main (int argc, char** argv) {
   int ncells = 777;
   bool imbalanced = false, prefer = false;
@@ -300,6 +361,8 @@ int main (int argc, char** argv) {
       cedr::caas::CAAS<> caas(p, ncells);
       nerr += drive("CAAS", caas, cts, ncells, imbalanced, false);
     }
+    nerr += pairing(p, cts, std::max(ncells, 2), 4);   // small trees: the two launches; from a few thousand groups on: fused
+    nerr += pairing(p, cts, 3000 + ncells, 4);
     bool threw = false;  // error convention: std::logic_error (cedr_util.hpp:70-77)
     try { cedr::caas::CAAS<> bad(p, 0); } catch (const std::logic_error&) { threw = true; }
     if ( ! threw) { std::printf("FAIL: CAAS with 0 cells did not throw\n"); ++nerr; }
