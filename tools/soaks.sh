@@ -12,5 +12,5 @@ run () {  # name, count
   tail -1 $O/$1.log
   return $rc
 }
-run soak_parity.py 60 && run soak_ranks_trees.py 400 && run soak_ranks.py 80 && run soak_zero_copy.py 200
+run soak_parity.py 60 && run soak_ranks_trees.py 400 && run soak_ranks.py 80 && run soak_zero_copy.py 200 && run soak_pairing.py 150
 cat $O/summary.txt
