@@ -1148,7 +1148,14 @@ void node_problem_sel (const double p_lo, const double p_orig, const double p_hi
   else node_problem_mass(p_lo, p_orig, p_hi, Qm, r0, lo0, or0, hi0, r1, lo1, or1, hi1, x0, x1, prefer);
 }
 
-template <int TW, bool ROWS>
+// CLS (round 5): the same kernel for the two other problem classes, whose tracers carry ONE field down the tree -- their
+// mass -- instead of {lo, orig, hi}: 1 = t-only (consistent without shapepreserve: every node's bounds are the global
+// q_min / q_max times its density, cedr_qlt.cpp:490-523,549-560; q bounds from the r2l rows behind the mass, as
+// qlt_down_micro_kernel reads them), 2 = nonnegative (cedr_qlt_inl.hpp:190-198). A mixed tracer list is swept class by
+// class, each launch over its range of the bulk order (tracers are grouped by type there, cedr_qlt.cpp:118-133), with the
+// problem class a compile-time constant: the node problem of each is what solve_node evaluates for it in
+// qlt_down_micro_kernel -- the same bits -- without the other classes' code and registers.
+template <int TW, bool ROWS, int CLS = 0>
 __global__ __launch_bounds__(kBlock, TW == 1 ? CEDR_DOWN_SP_WAVES1 : CEDR_DOWN_SP_WAVES2)
 void qlt_down_sp_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st,
                          double* __restrict__ l2r, double* __restrict__ r2l,
@@ -1180,6 +1187,7 @@ void qlt_down_sp_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st,
   int32_t* const fldL = reinterpret_cast<int32_t*>(outL + (ROWS ? L.nt : 0));
   int32_t* const r2lL = fldL + L.nt;
   int32_t* const onodeL = r2lL + L.nt;        // [<= kWave]
+  double* const qL = reinterpret_cast<double*>(onodeL + kWave);  // CLS 1: {q_min, q_max} of the chunk's tracers [TT][2]
   const int nleaf = tile.nleaf;
   const int64_t S = L.stride;
   const bool prefer = L.prefer_mass_con != 0;
@@ -1194,14 +1202,16 @@ void qlt_down_sp_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st,
   // The records {lo, orig, hi} of this lane's cells for this wave's tracers of chunk c, and the
   // assigned mass of tile output 'lane' (a micro tile has <= 64 outputs).
   // 'staged': the LDS copies of the tables are visible (not yet for the first chunk).
-  auto load = [&] (const int c, double (&cur)[TW][3][3], double (&X)[TW], const bool staged) {
+  auto load = [&] (const int c, double (&cur)[TW][3][3], double (&X)[TW], double (&Q)[TW][2], const bool staged) {
 #pragma unroll
     for (int s = 0; s < TW; ++s) {
       int bi = c*TT + wave + kNW*s;
       if (bi > nt - 1) bi = nt - 1;  // past the last tracer: re-read it (discarded)
-      const int field = staged ? fldL[bi] : L.bidx_l2r[bi];
+      // (one-field classes: the mass is the second field of a t-only tracer's record, the first of a nonnegative one's)
+      const int field = (staged ? fldL[bi] : L.bidx_l2r[bi]) - (CLS == 2 ? 1 : 0);
 #pragma unroll
       for (int f = 0; f < 3; ++f) {
+        if (CLS != 0 && f != 1) { cur[s][0][f] = cur[s][1][f] = cur[s][2][f] = 0.0; continue; }
         const double* __restrict__ const row =
           (ROWS ? (staged ? inL[field + f] : in_rows[field + f]) : l2r + static_cast<size_t>(field + f)*S) +
           diag_in0(tile.in0);
@@ -1210,7 +1220,25 @@ void qlt_down_sp_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st,
       }
       const int rb = staged ? r2lL[bi] : L.bidx_r2l[bi];
       X[s] = r2l[static_cast<size_t>(rb)*S + tile.out + (lane < tile.nout ? lane : tile.nout - 1)];
+      if (CLS == 1) {
+        Q[s][0] = r2l[static_cast<size_t>(rb + 1)*S + tile.out];
+        Q[s][1] = r2l[static_cast<size_t>(rb + 2)*S + tile.out];
+      } else {
+        Q[s][0] = Q[s][1] = 0.0;
+      }
     }
+  };
+  // The node problem of this kernel's class: rh = the parent's density (t-only: its bounds are q x density)
+  auto node_problem = [&] (const double rh, const double ql, const double qh, const double p_lo, const double p_orig,
+                           const double p_hi, const double Qm, const KidRho r0, const double lo0, const double or0,
+                           const double hi0, const KidRho r1, const double lo1, const double or1, const double hi1,
+                           double& x0, double& x1) {
+    if (CLS == 0)
+      node_problem_sel<true>(p_lo, p_orig, p_hi, Qm, r0, lo0, or0, hi0, r1, lo1, or1, hi1, x0, x1, prefer);
+    else if (CLS == 1)
+      solve_node(CONSISTENT, rh, ql, p_orig, qh, Qm, r0, ql, or0, qh, r1, ql, or1, qh, x0, x1, prefer);
+    else
+      solve_node(NONNEGATIVE, rh, 0.0, p_orig, 0.0, Qm, r0, 0.0, or0, 0.0, r1, 0.0, or1, 0.0, x0, x1, prefer);
   };
 
 #ifdef CEDR_STAMPS
@@ -1218,8 +1246,8 @@ void qlt_down_sp_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st,
   unsigned long long t_prev = __builtin_amdgcn_s_memtime();
   __builtin_amdgcn_s_waitcnt(0xC07F);
 #endif
-  double cur[TW][3][3], Xout[TW];
-  load(wi.c0, cur, Xout, false);
+  double cur[TW][3][3], Xout[TW], Qb[TW][2];
+  load(wi.c0, cur, Xout, Qb, false);
   if (ROWS) {
     for (int i = threadIdx.x; i < L.l2rndps; i += kBlock) inL[i] = in_rows[i];
     for (int i = threadIdx.x; i < nt; i += kBlock) outL[i] = out_rows[i];
@@ -1277,7 +1305,7 @@ void qlt_down_sp_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st,
     // loads and sums lead to the first barrier: above it. The LDS levels' node problems are done by
     // one or two waves while the others of the workgroup wait at a barrier: highest.
     __builtin_amdgcn_s_setprio(kPrioLoads);
-    if (c != wi.c0) load(c, cur, Xout, true);
+    if (c != wi.c0) load(c, cur, Xout, Qb, true);
 
 #ifdef CEDR_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(cur[0][0][0]), "+v"(cur[0][1][1]), "+v"(cur[0][2][2]), "+v"(Xout[0]) :: "memory");
@@ -1292,6 +1320,7 @@ void qlt_down_sp_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st,
       double* const Rw = recs + (wave + kNW*s)*pitch;
 #pragma unroll
       for (int f = 0; f < 3; ++f) {
+        if (CLS != 0 && f != 1) continue;
         const double t = cur[s][0][f] + cur[s][1][f];
         const double r = m.shape <= 0 ? cur[s][0][f] : (m.shape == 1 ? t : t + cur[s][2][f]);
         if (lane < nleaf) Rw[kRS*lane + f] = r;
@@ -1310,8 +1339,12 @@ void qlt_down_sp_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st,
           double* me = Rw + kRS*(nleaf + j);
           // (all six reads before the first write: the compiler must assume me aliases K0 / K1 and would
           // otherwise wait for LDS three times)
-          const double a0 = K0[0], a1 = K0[1], a2 = K0[2], b0 = K1[0], b1 = K1[1], b2 = K1[2];
-          me[0] = a0 + b0; me[1] = a1 + b1; me[2] = a2 + b2;
+          if (CLS != 0) {
+            me[1] = K0[1] + K1[1];
+          } else {
+            const double a0 = K0[0], a1 = K0[1], a2 = K0[2], b0 = K1[0], b1 = K1[1], b2 = K1[2];
+            me[0] = a0 + b0; me[1] = a1 + b1; me[2] = a2 + b2;
+          }
         }
       }
     }
@@ -1320,6 +1353,7 @@ void qlt_down_sp_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st,
     for (int s = 0; s < TW; ++s) {
       const int biw = c*TT + wave + kNW*s;
       if (biw < nt && lane < tile.nout) recs[(wave + kNW*s)*pitch + kRS*onodeL[lane] + 3] = Xout[s];
+      if (CLS == 1 && lane < 2) qL[2*(wave + kNW*s) + lane] = Qb[s][lane];
     }
     STAMP(2);  // sums + level sums
     __syncthreads();
@@ -1339,8 +1373,8 @@ void qlt_down_sp_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st,
         double* K0 = R + kRS*c0;
         double* K1 = R + kRS*c1;
         double x0, x1;
-        node_problem_sel<true>(P[0], P[1], P[2], P[3], r0, K0[0], K0[1], K0[2], r1, K1[0], K1[1], K1[2],
-                          x0, x1, prefer);
+        node_problem(rho3[3*me], CLS == 1 ? qL[2*tt] : 0.0, CLS == 1 ? qL[2*tt + 1] : 0.0, P[0], P[1], P[2], P[3],
+                     r0, K0[0], K0[1], K0[2], r1, K1[0], K1[1], K1[2], x0, x1);
         K0[3] = x0;
         K1[3] = x1;
       }
@@ -1364,21 +1398,29 @@ void qlt_down_sp_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st,
         // the micro root's sums, re-formed: three cells here, so t + p whatever the shape (no selects)
         const double RR[3] = {T[0] + cur[s][2][0], T[1] + cur[s][2][1], T[2] + cur[s][2][2]};
         const KidRho kp{cellrho[6*kWave + lane], cellrho[7*kWave + lane], cellrho[8*kWave + lane]};
+        const double rr = CLS == 1 ? rho3[3*lane] : 0.0;  // the micro root's density
         if (any2 && m.shape == 2)
-          node_problem_sel<true>(RR[0], RR[1], RR[2], Xr, kt, T[0], T[1], T[2],
-                            kp, cur[s][2][0], cur[s][2][1], cur[s][2][2], Xt, Xp, prefer);
+          node_problem(rr, Qb[s][0], Qb[s][1], RR[0], RR[1], RR[2], Xr, kt, T[0], T[1], T[2],
+                       kp, cur[s][2][0], cur[s][2][1], cur[s][2][2], Xt, Xp);
         if (any3 && m.shape == 3)
-          node_problem_sel<true>(RR[0], RR[1], RR[2], Xr, kp, cur[s][2][0], cur[s][2][1], cur[s][2][2],
-                            kt, T[0], T[1], T[2], Xp, Xt, prefer);
+          node_problem(rr, Qb[s][0], Qb[s][1], RR[0], RR[1], RR[2], Xr, kp, cur[s][2][0], cur[s][2][1], cur[s][2][2],
+                       kt, T[0], T[1], T[2], Xp, Xt);
       }
       if (m.shape >= 1) {
         const KidRho ku{cellrho[0*kWave + lane], cellrho[1*kWave + lane], cellrho[2*kWave + lane]};
         const KidRho kv{cellrho[3*kWave + lane], cellrho[4*kWave + lane], cellrho[5*kWave + lane]};
-        node_problem_sel<true>(T[0], T[1], T[2], Xt, ku, cur[s][0][0], cur[s][0][1], cur[s][0][2],
-                          kv, cur[s][1][0], cur[s][1][1], cur[s][1][2], Xu, Xv, prefer);
+        node_problem(kt.rh, Qb[s][0], Qb[s][1], T[0], T[1], T[2], Xt, ku, cur[s][0][0], cur[s][0][1], cur[s][0][2],
+                     kv, cur[s][1][0], cur[s][1][1], cur[s][1][2], Xu, Xv);
       }
       double* __restrict__ const orow = (ROWS ? outL[biw] : r2l + static_cast<size_t>(r2lL[biw])*S) + tile.in0;
       store_roles(orow, ro, Xu, Xv, Xp);
+      if (CLS == 1) {  // the q bounds go down with the masses (cedr_qlt.cpp:549-560), as in qlt_down_micro_kernel
+        double* __restrict__ dst = r2l + static_cast<size_t>(r2lL[biw])*S + tile.in0 + m.start;
+        double* __restrict__ l0p = l2r + static_cast<size_t>(fldL[biw])*S + tile.in0 + m.start;
+        for (int kc = 0; kc < m.size; ++kc) {
+          dst[S + kc] = Qb[s][0]; dst[2*S + kc] = Qb[s][1]; l0p[kc] = Qb[s][0]; l0p[2*S + kc] = Qb[s][1];
+        }
+      }
     }
     STAMP(5);  // register node problems + stores issued
   }
@@ -3286,7 +3328,8 @@ int cedr_hip_qlt_down_rows (const cedr_hip_qlt_layout* lay, const cedr_hip_stage
     // chunk's chain and not by occupancy -- take two tracers per wave, i.e. half the chunks; default 0 = none)
     static const int tw2_max = [] { const char* v = std::getenv("CEDR_HIP_SP_TW2_MAX_TILES"); return v ? std::atoi(v) : 0; }();
     if (sp && st->ntiles <= tw2_max) tw = 2;
-    if (const char* e = std::getenv("CEDR_HIP_MICRO_TW")) tw = std::atoi(e) == 1 ? 1 : 2;
+    int tw_env = 0;  // (CEDR_HIP_MICRO_TW set: the general kernel with that many tracers per wave, also for mixed lists)
+    if (const char* e = std::getenv("CEDR_HIP_MICRO_TW")) { tw = std::atoi(e) == 1 ? 1 : 2; tw_env = tw; }
     const int TTm = kNW*tw;
     const size_t ldsm = sizeof(double)*(meta_doubles(st) + 3*mn + kCellRho*kWave +
                                         static_cast<size_t>(TTm)*pitch) +
@@ -3302,21 +3345,53 @@ int cedr_hip_qlt_down_rows (const cedr_hip_qlt_layout* lay, const cedr_hip_stage
       return 0;
     };
     int e;
-    if (sp) {
+    // Mixed tracer lists (round 5): class by class through the class-specialised forms of the shape-preserving kernel
+    // (qlt_down_sp_kernel<1, ROWS, CLS>), each over its range of the bulk order, when the layout says how many tracers
+    // of each class there are (class_count; CEDR_HIP_DOWN_CLS=0: the general kernel instead).
+    static const bool cls_on = [] { const char* v = std::getenv("CEDR_HIP_DOWN_CLS"); return ! v || std::atoi(v) != 0; }();
+    const bool by_class = ! sp && sp_on && cls_on && tw_env == 0 &&
+      lay->class_count[0] + lay->class_count[1] + lay->class_count[2] == nt &&
+      lay->class_count[0] >= 0 && lay->class_count[1] >= 0 && lay->class_count[2] >= 0;
+    if (sp || by_class) {
       const int pitchs = pitch;
-      const size_t ldss = ldsm + sizeof(int32_t)*(2*static_cast<size_t>(nt) + kWave);
-      if (ldss > 160*1024) return static_cast<int>(hipErrorInvalidValue);
-      auto gosp = [&] (auto kernel) -> int {
+      auto gosp = [&] (auto kernel, const cedr_hip_qlt_layout& Lc, double* const* out_rows_c, const int twc) -> int {
+        const int TTc = kNW*twc;
+        const size_t ldss = sizeof(double)*(meta_doubles(st) + 3*mn + kCellRho*kWave + static_cast<size_t>(TTc)*pitch) +
+          (in_rows ? sizeof(double*)*static_cast<size_t>(Lc.l2rndps + Lc.nt) : 0) +
+          sizeof(int32_t)*(2*static_cast<size_t>(Lc.nt) + kWave) + sizeof(double)*2*static_cast<size_t>(TTc);
+        if (ldss > 160*1024) return static_cast<int>(hipErrorInvalidValue);
         int e2 = set_lds_limit(kernel, ldss);
         if (e2) return e2;
-        const TailSplit tail = tail_split(kernel, ldss, st, (nt + TTm - 1)/TTm, gridm.y);
-        hipLaunchKernelGGL(kernel, dim3(xcd_grid_tail(st->ntiles, tail), gridm.y), dim3(kBlock), ldss, stream,
-                           *lay, *st, l2r, r2l, in_rows, out_rows, nrow, pitchs, tail);
+        const int nch = (Lc.nt + TTc - 1)/TTc;
+        const unsigned gy = chunk_split(st->ntiles, nch, split_down, true);
+        const TailSplit tail = tail_split(kernel, ldss, st, nch, gy);
+        hipLaunchKernelGGL(kernel, dim3(xcd_grid_tail(st->ntiles, tail), gy), dim3(kBlock), ldss, stream,
+                           Lc, *st, l2r, r2l, in_rows, out_rows_c, nrow, pitchs, tail);
         return 0;
       };
-      if (tw == 1) e = in_rows ? gosp(qlt_down_sp_kernel<1, true>) : gosp(qlt_down_sp_kernel<1, false>);
-      else e = in_rows ? gosp(qlt_down_sp_kernel<2, true>) : gosp(qlt_down_sp_kernel<2, false>);
-      if (e) return e;
+      if (sp) {
+        if (tw == 1) e = in_rows ? gosp(qlt_down_sp_kernel<1, true>, *lay, out_rows, 1) : gosp(qlt_down_sp_kernel<1, false>, *lay, out_rows, 1);
+        else e = in_rows ? gosp(qlt_down_sp_kernel<2, true>, *lay, out_rows, 2) : gosp(qlt_down_sp_kernel<2, false>, *lay, out_rows, 2);
+        if (e) return e;
+        return launch_status();
+      }
+      int off = 0;
+      for (int cls = 0; cls < 3; ++cls) {
+        const int cnt = lay->class_count[cls];
+        if (cnt == 0) continue;
+#ifdef CEDR_PROF_BY_CLASS  // (diagnostic builds: one profiler record per class launch, aux = tiles + (class + 1) * 2^24)
+        ProfScope psc(K_QLT_DOWN, st->ntiles + (static_cast<int64_t>(cls + 1) << 24), stream);
+#endif
+        cedr_hip_qlt_layout Lc = *lay;
+        Lc.nt = cnt;
+        Lc.bidx_prob += off; Lc.bidx_l2r += off; Lc.bidx_r2l += off;
+        double* const* const orc = out_rows ? out_rows + off : nullptr;
+        if (cls == 0) e = in_rows ? gosp(qlt_down_sp_kernel<1, true, 0>, Lc, orc, 1) : gosp(qlt_down_sp_kernel<1, false, 0>, Lc, orc, 1);
+        else if (cls == 1) e = in_rows ? gosp(qlt_down_sp_kernel<1, true, 1>, Lc, orc, 1) : gosp(qlt_down_sp_kernel<1, false, 1>, Lc, orc, 1);
+        else e = in_rows ? gosp(qlt_down_sp_kernel<1, true, 2>, Lc, orc, 1) : gosp(qlt_down_sp_kernel<1, false, 2>, Lc, orc, 1);
+        if (e) return e;
+        off += cnt;
+      }
       return launch_status();
     }
     if (tw == 1) e = in_rows ? go(qlt_down_micro_kernel<1, true>) : go(qlt_down_micro_kernel<1, false>);

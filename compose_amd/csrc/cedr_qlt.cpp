@@ -272,6 +272,10 @@ void QLTHip::finish_setup () {
   d.lay.bidx_r2l = d.bidx_r2l.data();
   d.lay.l2r_op = d.l2r_op.data();
   d.lay.flags = 0;
+  // tracers per class in bulk order: problem type indices st, cst | t, ct | nn, cnn (cedr_qlt_inl.hpp:103-105)
+  d.lay.class_count[0] = md_.prob2trcrptr[2];
+  d.lay.class_count[1] = md_.prob2trcrptr[4] - md_.prob2trcrptr[2];
+  d.lay.class_count[2] = md_.prob2trcrptr[6] - md_.prob2trcrptr[4];
   {
     bool all_sp = get_num_tracers() > 0;
     for (const Int pt : md_.trcr2prob) if ( ! (pt & ProblemType::shapepreserve)) all_sp = false;

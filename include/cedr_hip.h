@@ -83,6 +83,10 @@ typedef struct {
   const uint8_t* l2r_op;     /* [l2rndps] 0 sum, 1 min, 2 max per field */
   int32_t flags;             /* bit 0: every tracer is shape preserving (s, st, cs, cst): the
                               * root->leaves sweep may use the kernel specialised for that */
+  int32_t class_count[3];    /* tracers per problem class in bulk order -- shape preserving first, then t-only
+                              * (consistent without shapepreserve), then nonnegative (the reference's bulk order,
+                              * cedr_qlt.cpp:118-133): a mixed list is then swept class by class with
+                              * class-specialised kernels. All zero = not given (one general kernel) */
 } cedr_hip_qlt_layout;
 enum { CEDR_QLT_ALL_SHAPEPRESERVE = 1 };
 
