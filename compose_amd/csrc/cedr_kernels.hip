@@ -3110,13 +3110,15 @@ Profiler g_prof;
 struct ProfScope {
   hipStream_t s;
   bool on;
-  ProfScope (int id, int64_t aux, hipStream_t stream) : s(stream), on(g_prof.on) {
+  size_t idx;  // (its own record: scopes may nest)
+  ProfScope (int id, int64_t aux, hipStream_t stream) : s(stream), on(g_prof.on), idx(0) {
     if ( ! on) return;
     ProfRec r{id, aux, g_prof.get(), g_prof.get()};
     (void) hipEventRecord(r.a, s);
+    idx = g_prof.recs.size();
     g_prof.recs.push_back(r);
   }
-  ~ProfScope () { if (on) (void) hipEventRecord(g_prof.recs.back().b, s); }
+  ~ProfScope () { if (on && idx < g_prof.recs.size()) (void) hipEventRecord(g_prof.recs[idx].b, s); }
 };
 
 inline int launch_status () { return static_cast<int>(hipGetLastError()); }
