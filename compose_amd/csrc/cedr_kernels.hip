@@ -1414,12 +1414,16 @@ void qlt_down_sp_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st,
       }
       double* __restrict__ const orow = (ROWS ? outL[biw] : r2l + static_cast<size_t>(r2lL[biw])*S) + tile.in0;
       store_roles(orow, ro, Xu, Xv, Xp);
-      if (CLS == 1) {  // the q bounds go down with the masses (cedr_qlt.cpp:549-560), as in qlt_down_micro_kernel
+      // The q bounds go down with the masses (cedr_qlt.cpp:549-560): the stage below reads them at its tiles' outputs.
+      // Below the CELLS there is no stage: nothing reads a cell's bound rows again (get_Qm reads the mass row, the next
+      // step's set_Qm rewrites the l2r bounds), so the launch over the cells leaves them out unless asked
+      // (CEDR_QLT_LEAF_BOUNDS in the layout's flags; they are 4 of the 5 rows such a tracer's launch would write).
+      if (CLS == 1 && ( ! (L.flags & CEDR_QLT_LEAF_STAGE) || (L.flags & CEDR_QLT_LEAF_BOUNDS))) {
         double* __restrict__ dst = r2l + static_cast<size_t>(r2lL[biw])*S + tile.in0 + m.start;
         double* __restrict__ l0p = l2r + static_cast<size_t>(fldL[biw])*S + tile.in0 + m.start;
-        for (int kc = 0; kc < m.size; ++kc) {
-          dst[S + kc] = Qb[s][0]; dst[2*S + kc] = Qb[s][1]; l0p[kc] = Qb[s][0]; l0p[2*S + kc] = Qb[s][1];
-        }
+        const double ql = Qb[s][0], qh = Qb[s][1];
+        store_cells(dst + S, m.size, ql, ql, ql); store_cells(dst + 2*S, m.size, qh, qh, qh);
+        store_cells(l0p, m.size, ql, ql, ql); store_cells(l0p + 2*S, m.size, qh, qh, qh);
       }
     }
     STAMP(5);  // register node problems + stores issued
@@ -3139,6 +3143,7 @@ int set_lds_limit (K kernel, size_t bytes) {
 constexpr int kUpFT = CEDR_UP_FT;
 constexpr int kUpFT32MaxTiles = 0;  // stages of at most this many tiles take 32 fields per chunk (0: none)
 constexpr int kDownTT = 8;   // tracers per chunk, root->leaves
+constexpr int kClsMinTiles = 2048;  // mixed tracer lists: smallest launch that is swept class by class
 
 // kid pairs (4 B each) + level offsets (4 B each), rounded up to doubles
 inline size_t meta_doubles (const cedr_hip_stage* st) { return static_cast<size_t>(st->max_nint) + 1; }
@@ -3351,7 +3356,10 @@ int cedr_hip_qlt_down_rows (const cedr_hip_qlt_layout* lay, const cedr_hip_stage
     // (qlt_down_sp_kernel<1, ROWS, CLS>), each over its range of the bulk order, when the layout says how many tracers
     // of each class there are (class_count; CEDR_HIP_DOWN_CLS=0: the general kernel instead).
     static const bool cls_on = [] { const char* v = std::getenv("CEDR_HIP_DOWN_CLS"); return ! v || std::atoi(v) != 0; }();
-    const bool by_class = ! sp && sp_on && cls_on && tw_env == 0 &&
+    // (only launches of at least kClsMinTiles tiles: three launches over a small stage cost more in launch gaps and
+    // per-tile setup than the general kernel's slower chunks -- 1024 tiles: 0.094 against 0.077 ms, 64: 0.055 against 0.014)
+    static const int cls_min = [] { const char* v = std::getenv("CEDR_HIP_DOWN_CLS_MIN_TILES"); return v ? std::atoi(v) : kClsMinTiles; }();
+    const bool by_class = ! sp && sp_on && cls_on && tw_env == 0 && st->ntiles >= cls_min &&
       lay->class_count[0] + lay->class_count[1] + lay->class_count[2] == nt &&
       lay->class_count[0] >= 0 && lay->class_count[1] >= 0 && lay->class_count[2] >= 0;
     if (sp || by_class) {

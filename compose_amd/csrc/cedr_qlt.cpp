@@ -48,6 +48,8 @@ struct QLTHip::Impl {
   hipEvent_t down_ev = nullptr;     // see QLTHip::sweep_down_event
   hipEvent_t mid_ev = nullptr;      // see QLTHip::sweep_mid_event
   std::string placement;            // see QLTHip::placement_report
+  // CEDR_HIP_LEAF_BOUNDS=1: the cells' q-bound rows of t-only tracers are written as the reference leaves them
+  int leaf_flags = [] { const char* v = std::getenv("CEDR_HIP_LEAF_BOUNDS"); return (v && std::atoi(v) != 0) ? CEDR_QLT_LEAF_BOUNDS : 0; }();
   ~Impl () { if (down_ev) (void) hipEventDestroy(down_ev); if (mid_ev) (void) hipEventDestroy(mid_ev); }
 };
 
@@ -534,7 +536,9 @@ void QLTHip::run () {
       continue;
     }
     const bool rows = rows_mode && i == 1;
-    cedr_k_check(cedr_hip_qlt_down_rows(&d.lay, &loc[i-1]->h, d.l2r, d.r2l,
+    cedr_hip_qlt_layout lay = d.lay;
+    if (i == 1) lay.flags |= CEDR_QLT_LEAF_STAGE | d.leaf_flags;  // the launch over the cells
+    cedr_k_check(cedr_hip_qlt_down_rows(&lay, &loc[i-1]->h, d.l2r, d.r2l,
                                         rows ? d.in_rows.data() : nullptr,
                                         rows ? d.out_rows.data() : nullptr, nlclcells(), s));
   }

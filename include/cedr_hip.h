@@ -88,7 +88,11 @@ typedef struct {
                               * cedr_qlt.cpp:118-133): a mixed list is then swept class by class with
                               * class-specialised kernels. All zero = not given (one general kernel) */
 } cedr_hip_qlt_layout;
-enum { CEDR_QLT_ALL_SHAPEPRESERVE = 1 };
+enum { CEDR_QLT_ALL_SHAPEPRESERVE = 1,
+/* set by the caller for the launch whose inputs are the CELLS (a plan's first local stage): below them no stage reads the
+ * q bounds a t-only tracer's sweep hands down (cedr_qlt.cpp:549-560), so the class-specialised kernel does not write the
+ * cells' bound rows -- unless CEDR_QLT_LEAF_BOUNDS asks for the reference's full post-run state of l2r / r2l */
+       CEDR_QLT_LEAF_STAGE = 2, CEDR_QLT_LEAF_BOUNDS = 4 };
 
 /* Leaves->root sweep of `nfields` independent fields over one stage: every
  * internal node gets op(kid0, kid1); only tile roots are written back.
