@@ -1155,8 +1155,11 @@ void node_problem_sel (const double p_lo, const double p_orig, const double p_hi
 // class, each launch over its range of the bulk order (tracers are grouped by type there, cedr_qlt.cpp:118-133), with the
 // problem class a compile-time constant: the node problem of each is what solve_node evaluates for it in
 // qlt_down_micro_kernel -- the same bits -- without the other classes' code and registers.
+#ifndef CEDR_DOWN_CLS1_WAVES
+# define CEDR_DOWN_CLS1_WAVES 5  // waves per SIMD the t-only form is compiled for
+#endif
 template <int TW, bool ROWS, int CLS = 0>
-__global__ __launch_bounds__(kBlock, TW == 1 ? CEDR_DOWN_SP_WAVES1 : CEDR_DOWN_SP_WAVES2)
+__global__ __launch_bounds__(kBlock, TW == 1 ? (CLS == 1 ? CEDR_DOWN_CLS1_WAVES : CEDR_DOWN_SP_WAVES1) : CEDR_DOWN_SP_WAVES2)
 void qlt_down_sp_kernel (const cedr_hip_qlt_layout L, const cedr_hip_stage st,
                          double* __restrict__ l2r, double* __restrict__ r2l,
                          const double* const* __restrict__ in_rows,
