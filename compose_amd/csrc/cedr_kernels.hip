@@ -3358,10 +3358,13 @@ int cedr_hip_qlt_down_rows (const cedr_hip_qlt_layout* lay, const cedr_hip_stage
     // Mixed tracer lists (round 5): class by class through the class-specialised forms of the shape-preserving kernel
     // (qlt_down_sp_kernel<1, ROWS, CLS>), each over its range of the bulk order, when the layout says how many tracers
     // of each class there are (class_count; CEDR_HIP_DOWN_CLS=0: the general kernel instead).
-    static const bool cls_on = [] { const char* v = std::getenv("CEDR_HIP_DOWN_CLS"); return ! v || std::atoi(v) != 0; }();
+    // (the two knobs travel in the layout's flags, read from the environment when the QLT is set up: CEDR_HIP_DOWN_CLS=0,
+    // CEDR_HIP_DOWN_CLS_MIN_TILES)
+    const bool cls_on = ! (lay->flags & CEDR_QLT_NO_CLASS_FORMS);
     // (only launches of at least kClsMinTiles tiles: three launches over a small stage cost more in launch gaps and
     // per-tile setup than the general kernel's slower chunks -- 1024 tiles: 0.094 against 0.077 ms, 64: 0.055 against 0.014)
-    static const int cls_min = [] { const char* v = std::getenv("CEDR_HIP_DOWN_CLS_MIN_TILES"); return v ? std::atoi(v) : kClsMinTiles; }();
+    const int cls_min_f = (lay->flags >> 8) & 0xffff;
+    const int cls_min = cls_min_f ? cls_min_f : kClsMinTiles;
     const bool by_class = ! sp && sp_on && cls_on && tw_env == 0 && st->ntiles >= cls_min &&
       lay->class_count[0] + lay->class_count[1] + lay->class_count[2] == nt &&
       lay->class_count[0] >= 0 && lay->class_count[1] >= 0 && lay->class_count[2] >= 0;

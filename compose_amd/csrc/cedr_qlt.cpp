@@ -283,6 +283,10 @@ void QLTHip::finish_setup () {
     for (const Int pt : md_.trcr2prob) if ( ! (pt & ProblemType::shapepreserve)) all_sp = false;
     if (all_sp) d.lay.flags |= CEDR_QLT_ALL_SHAPEPRESERVE;
   }
+  // mixed lists: the class-specialised root->leaves forms (cedr_hip_qlt_down_rows), knobs read here once per QLT
+  if (const char* e = std::getenv("CEDR_HIP_DOWN_CLS")) if (std::atoi(e) == 0) d.lay.flags |= CEDR_QLT_NO_CLASS_FORMS;
+  if (const char* e = std::getenv("CEDR_HIP_DOWN_CLS_MIN_TILES"))
+    d.lay.flags |= (std::max(1, std::min(0xffff, std::atoi(e)))) << 8;
   if ( ! d.inited) {
     // Own allocation: only what this build's layout touches (fields x stride). That is about
     // half of the reference's figure, which get_buffers_sizes reports for callers who bring

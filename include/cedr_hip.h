@@ -92,7 +92,10 @@ enum { CEDR_QLT_ALL_SHAPEPRESERVE = 1,
 /* set by the caller for the launch whose inputs are the CELLS (a plan's first local stage): below them no stage reads the
  * q bounds a t-only tracer's sweep hands down (cedr_qlt.cpp:549-560), so the class-specialised kernel does not write the
  * cells' bound rows -- unless CEDR_QLT_LEAF_BOUNDS asks for the reference's full post-run state of l2r / r2l */
-       CEDR_QLT_LEAF_STAGE = 2, CEDR_QLT_LEAF_BOUNDS = 4 };
+       CEDR_QLT_LEAF_STAGE = 2, CEDR_QLT_LEAF_BOUNDS = 4,
+/* mixed tracer lists: never sweep class by class (the general kernel for every launch); bits 8..23 of flags, if not 0:
+ * the smallest launch, in tiles, that is swept class by class (default 2048) */
+       CEDR_QLT_NO_CLASS_FORMS = 8 };
 
 /* Leaves->root sweep of `nfields` independent fields over one stage: every
  * internal node gets op(kid0, kid1); only tile roots are written back.

@@ -316,3 +316,31 @@ def test_tail_split_does_not_change_results(gpu, oracle, monkeypatch):
             got = common.run_hip_qlt(ca, q, v)
             assert np.array_equal(got, want), (len(trs), tail, rounds)
             del q
+
+
+def test_mixed_types_class_forms_at_scale(gpu, oracle, monkeypatch):
+    """A mixed tracer list at a size whose first stage has >= 2048 tiles: the root->leaves launch over the cells is swept
+    class by class with the class-specialised forms of the shape-preserving kernel (shape preserving / t-only /
+    nonnegative; cedr_qlt.cpp:490-523,549-560, cedr_qlt_inl.hpp:190-198), the smaller stages by the general kernel:
+    bit-identical to the oracle, to the general kernel alone (CEDR_HIP_DOWN_CLS=0), and with the cells' bound rows of
+    t-only tracers written as the reference leaves them (CEDR_HIP_LEAF_BOUNDS=1)."""
+    ca = gpu
+    n = 400000
+    trs = R.tracers_vector()[:12]  # all six problem types, two perturbations
+    types = [t.problem_type for t in trs]
+    v = R.make_values(trs, n, seed=2026)
+    want = common.run_oracle_qlt(oracle, (False, False), n, 1, types, v)
+    outs = []
+    for env in ({}, {"CEDR_HIP_DOWN_CLS": "0"}, {"CEDR_HIP_LEAF_BOUNDS": "1"}):
+        for k, val in env.items():
+            monkeypatch.setenv(k, val)
+        q = common.make_hip_qlt(ca, ca.Tree.make_1d(n), n, types)
+        if not env and common.default_knobs():
+            assert len(q.plan()["local"][0]["tiles"]) >= 2048
+        outs.append(common.run_hip_qlt(ca, q, v))
+        for k in env:
+            monkeypatch.delenv(k)
+        del q
+    for got in outs:
+        assert np.array_equal(got, want)
+    assert R.check(trs, v, outs[0], False, verbose=False)[0] == 0
