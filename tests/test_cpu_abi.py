@@ -55,3 +55,17 @@ def test_library_carries_the_sha_of_its_kernel_source():
     import compose_amd as ca
     src = os.path.join(os.path.dirname(os.path.abspath(ca.__file__)), "csrc", "cedr_kernels.hip")
     assert ca.kernels_sha256() == hashlib.sha256(open(src, "rb").read()).hexdigest()
+
+
+def test_rehearsal_communicator_surface():
+    """make_parallel_rehearsal (cedr_mpi.hpp): rank 0 of P over a communicator of ONE real rank; anything else is refused."""
+    import compose_amd as ca
+    p = ca.Parallel.rehearsal(ca.Parallel.self_(), 8)
+    assert p.size() == 8 and p.rank() == 0
+    with pytest.raises(ca.CedrError, match="one rank"):
+        ca.Parallel.rehearsal(ca.Parallel.callbacks(0, 2, lambda *a: 0, lambda *a: 0), 4)
+    with pytest.raises(ca.CedrError):
+        ca.Parallel.rehearsal(ca.Parallel.self_(), 0)
+    # a QLT over it plans as rank 0 of 8: one eighth of the cells, boundary exchange + apex tile
+    q = ca.QLT(p, 8000, ca.Tree.make_1d(8000, 8, False, False))
+    assert q.nlclcells() == 1000 and q.plan()["nb_max"] >= 1
