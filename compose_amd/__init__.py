@@ -69,6 +69,9 @@ _SIGS = {
     "cedr_rccl_get_unique_id": (C.c_int, [_vp]),
     "cedr_parallel_create_rccl": (_vp, [_vp, C.c_int, C.c_int]),
     "cedr_parallel_create_rehearsal": (_vp, [_vp, C.c_int]),
+    "cedr_peer_mailbox_create": (_vp, [C.c_int, C.c_size_t, _vp]),
+    "cedr_peer_mailbox_destroy": (None, [_vp]),
+    "cedr_parallel_create_peer_flags": (_vp, [_vp, _vp, C.c_int, C.c_int]),
     "cedr_parallel_create_callbacks": (_vp, [C.c_int, C.c_int, ALLGATHER_FN, ALLREDUCE_FN, _vp]),
     "cedr_parallel_create_callbacks_p2p": (_vp, [C.c_int, C.c_int, ALLGATHER_FN, ALLREDUCE_FN, EXCHANGE_FN, _vp]),
     "cedr_parallel_exchange": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
@@ -361,6 +364,21 @@ def node_problem_batch(problem_type, rhom, pd, Qm, rhom0, k0d, rhom1, k1d, prefe
     return dout.numpy((len(rec), 2))
 
 
+class PeerMailbox:
+    """A rank's mailbox of the peer-flag transport (Parallel.peer_mailbox)."""
+
+    def __init__(self, handle):
+        self.h = _handle(handle, "PeerMailbox")
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                lib().cedr_peer_mailbox_destroy(self.h)
+                self.h = None
+        except Exception:  # noqa: BLE001 -- interpreter shutdown
+            pass
+
+
 class Parallel:
     """cedr::mpi::Parallel (reference cedr/cedr_mpi.hpp:17-27)."""
 
@@ -383,6 +401,25 @@ class Parallel:
         collectives run through `inner` for real, the other ranks' all-gather blocks are copies of this rank's.
         What one GPU can run of an N-GPU job (measurements, tests)."""
         return Parallel(lib().cedr_parallel_create_rehearsal(inner.h, int(pretended_size)), keep=inner)
+
+    PEER_HANDLE_BYTES = 96
+
+    @staticmethod
+    def peer_mailbox(size, slot_doubles=4096):
+        """This rank's mailbox for the peer-flag transport (cedr_mpi.hpp): returns (mailbox, handle bytes). The launcher
+        gathers every rank's handle (rank order) and hands them to peer_flags()."""
+        buf = C.create_string_buffer(Parallel.PEER_HANDLE_BYTES)
+        return PeerMailbox(lib().cedr_peer_mailbox_create(int(size), int(slot_doubles), buf)), buf.raw
+
+    @staticmethod
+    def peer_flags(mailbox, handles, rank, size):
+        """One process per GPU of one node over stream-ordered stores into the peers' mailboxes (no communicator
+        library): `handles` = the ranks' handle bytes in rank order (a list, or already concatenated)."""
+        blob = b"".join(handles) if isinstance(handles, (list, tuple)) else bytes(handles)
+        if len(blob) != Parallel.PEER_HANDLE_BYTES * int(size):
+            raise CedrError("peer_flags: %d bytes of handles for %d ranks" % (len(blob), size))
+        buf = C.create_string_buffer(blob, len(blob))
+        return Parallel(lib().cedr_parallel_create_peer_flags(mailbox.h, buf, int(rank), int(size)), keep=mailbox)
 
     @staticmethod
     def rccl_unique_id():

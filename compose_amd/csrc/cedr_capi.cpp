@@ -28,6 +28,7 @@ struct NsBox { tree::NodeSets::ConstPtr owned; const tree::NodeSets* ns; };
 struct PlanBox { plan::Plan owned; const plan::Plan* p; int64_t stride; };
 struct QltBox { std::unique_ptr<qlt::QLTHip> q; NsBox ns; PlanBox plan; };
 struct BfbBox { std::shared_ptr<BfbTreeAllReducerHip> b; };
+struct MailboxBox { std::shared_ptr<mpi::PeerMailbox> m; };
 
 struct CbReducer : public caas::CAASHip::UserAllReducer {
   cedr_user_allreduce_fn fn; int nacc; void* user;
@@ -60,6 +61,22 @@ void* cedr_parallel_create_rehearsal (void* inner, int pretended_size) {
   CEDR_TRY
   cedr_throw_if( ! inner, "cedr_parallel_create_rehearsal needs an inner Parallel");
   return new ParallelBox{mpi::make_parallel_rehearsal(static_cast<ParallelBox*>(inner)->p, pretended_size)};
+  CEDR_CATCH(nullptr)
+}
+void* cedr_peer_mailbox_create (int size, size_t slot_doubles, void* handle_out) {
+  CEDR_TRY
+  static_assert(CEDR_PEER_HANDLE_BYTES == mpi::kPeerHandleBytes, "handle size");
+  cedr_throw_if( ! handle_out, "cedr_peer_mailbox_create needs room for the handle");
+  auto mb = mpi::peer_mailbox_create(size, slot_doubles);
+  mpi::peer_mailbox_handle(*mb, handle_out);
+  return new MailboxBox{mb};
+  CEDR_CATCH(nullptr)
+}
+void cedr_peer_mailbox_destroy (void* mailbox) { delete static_cast<MailboxBox*>(mailbox); }
+void* cedr_parallel_create_peer_flags (void* my_mailbox, const void* handles, int rank, int size) {
+  CEDR_TRY
+  cedr_throw_if( ! my_mailbox || ! handles, "cedr_parallel_create_peer_flags needs a mailbox and the ranks' handles");
+  return new ParallelBox{mpi::make_parallel_peer_flags(static_cast<MailboxBox*>(my_mailbox)->m, handles, rank, size)};
   CEDR_CATCH(nullptr)
 }
 void* cedr_parallel_create_callbacks (int rank, int size, cedr_allgather_fn ag,

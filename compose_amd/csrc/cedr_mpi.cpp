@@ -4,6 +4,10 @@
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
+#include <unistd.h>
+
+#include <algorithm>
+#include <cstdint>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -26,6 +30,73 @@ __global__ void rehearsal_replicate_kernel (Real* __restrict__ recv, const size_
   for (int r = 1; r < nblocks; ++r) recv[static_cast<size_t>(r)*count + i] = v;
 }
 #endif
+
+// PeerFlagComm's kernels. A mailbox is [2 counters, padded to kMailboxHead bytes][2 parities][P sources][cap doubles].
+constexpr size_t kMailboxHead = 128;
+struct PeerTable { unsigned char* base[kPeerFlagsMaxRanks]; };
+#ifdef __HIPCC__
+// Workgroup r stores this rank's block into its slot of rank r's mailbox, then announces it: every thread's stores are
+// released to system scope before thread 0 adds 1 to that mailbox's counter of this parity.
+__global__ void peer_put_kernel (const PeerTable t, const Real* __restrict__ send, const size_t count,
+                                 const size_t slot_off, const int parity) {
+  unsigned char* const mb = t.base[blockIdx.x];
+  unsigned long long* const dst = reinterpret_cast<unsigned long long*>(mb + kMailboxHead) + slot_off;
+  const unsigned long long* const src = reinterpret_cast<const unsigned long long*>(send);
+  for (size_t i = threadIdx.x; i < count; i += blockDim.x)
+    __hip_atomic_store(dst + i, src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0)
+    __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(mb) + parity, 1ull, __ATOMIC_RELEASE,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// After the wait on this rank's counter: recv = the P slots one after the other (sum == 0), or their sum in rank
+// order (sum == 1: ((s0 + s1) + s2) + ..., the same expression on every rank, hence the same bits).
+__global__ void peer_take_kernel (const unsigned char* __restrict__ mb, Real* __restrict__ recv, const size_t count,
+                                  const size_t parity_off, const size_t cap, const int nranks, const int sum,
+                                  const size_t block /* all-gather: doubles between two ranks' blocks in recv */) {
+  const size_t i = static_cast<size_t>(blockIdx.x)*blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const unsigned long long* const slots = reinterpret_cast<const unsigned long long*>(mb + kMailboxHead) + parity_off;
+  Real acc = 0;
+  for (int r = 0; r < nranks; ++r) {
+    const unsigned long long bits = __hip_atomic_load(slots + static_cast<size_t>(r)*cap + i, __ATOMIC_RELAXED,
+                                                      __HIP_MEMORY_SCOPE_SYSTEM);
+    const Real v = __longlong_as_double(static_cast<long long>(bits));
+    if (sum) acc = r == 0 ? v : acc + v;
+    else recv[static_cast<size_t>(r)*block + i] = v;
+  }
+  if (sum) recv[i] = acc;
+}
+#endif
+
+// Collectives of ONE communicator must execute in the same order on every rank. Callers issue
+// them in program order, but possibly on different streams (QLT and CAAS each on its own): every
+// collective therefore waits for the previous one's completion event when the stream changes,
+// so the order of execution is the order of issue whatever the streams are.
+struct CrossStreamOrder {
+  hipEvent_t done_ = nullptr;
+  hipStream_t last_ = nullptr;
+  bool used_ = false;
+  ~CrossStreamOrder () { if (done_) (void) hipEventDestroy(done_); }
+  // Both return 0 or a HIP error: a collective whose ordering could not be set up must fail, not run
+  // concurrently with another one on the same communicator.
+  int before (hipStream_t s) {
+    if (used_ && s != last_) return static_cast<int>(hipStreamWaitEvent(s, done_, 0));
+    return 0;
+  }
+  int after (hipStream_t s) {
+    if ( ! done_) {
+      const hipError_t e = hipEventCreateWithFlags(&done_, hipEventDisableTiming);
+      if (e != hipSuccess) { done_ = nullptr; return static_cast<int>(e); }
+    }
+    const hipError_t e = hipEventRecord(done_, s);
+    if (e != hipSuccess) return static_cast<int>(e);
+    last_ = s;
+    used_ = true;
+    return 0;
+  }
+};
 
 // ------------------------------------------------------------------ single rank
 struct SelfComm : public Comm {
@@ -96,30 +167,9 @@ const RcclApi& rccl () {
 struct RcclComm : public Comm {
   ncclComm_t comm_;
   int rank_, size_;
-  // Collectives of ONE communicator must execute in the same order on every rank. Callers issue
-  // them in program order, but possibly on different streams (QLT and CAAS each on its own): every
-  // collective therefore waits for the previous one's completion event when the stream changes,
-  // so the order of execution is the order of issue whatever the streams are.
-  hipEvent_t done_ = nullptr;
-  hipStream_t last_ = nullptr;
-  bool used_ = false;
-  // Both return 0 or a HIP error: a collective whose ordering could not be set up must fail, not run
-  // concurrently with another one on the same communicator.
-  int order_before (hipStream_t s) {
-    if (used_ && s != last_) return static_cast<int>(hipStreamWaitEvent(s, done_, 0));
-    return 0;
-  }
-  int order_after (hipStream_t s) {
-    if ( ! done_) {
-      const hipError_t e = hipEventCreateWithFlags(&done_, hipEventDisableTiming);
-      if (e != hipSuccess) { done_ = nullptr; return static_cast<int>(e); }
-    }
-    const hipError_t e = hipEventRecord(done_, s);
-    if (e != hipSuccess) return static_cast<int>(e);
-    last_ = s;
-    used_ = true;
-    return 0;
-  }
+  CrossStreamOrder ord_;  // collectives issued on different streams still execute in the order of issue
+  int order_before (hipStream_t s) { return ord_.before(s); }
+  int order_after (hipStream_t s) { return ord_.after(s); }
   RcclComm (const void* id, int rank, int size) : comm_(nullptr), rank_(rank), size_(size) {
     const RcclApi& a = rccl();
     cedr_throw_if( ! a.ok, "librccl could not be loaded");
@@ -130,7 +180,6 @@ struct RcclComm : public Comm {
   }
   ~RcclComm () override {
     if (comm_) rccl().CommDestroy(comm_);
-    if (done_) (void) hipEventDestroy(done_);
   }
   int rank () const override { return rank_; }
   int size () const override { return size_; }
@@ -193,6 +242,108 @@ struct CallbackComm : public Comm {
   }
 };
 
+// ------------------------------------------------------------------ peer flags
+struct PeerHandle {  // what a rank publishes: kPeerHandleBytes
+  hipIpcMemHandle_t ipc;
+  int64_t pid;
+  uint64_t ptr, nranks, cap;
+};
+static_assert(sizeof(PeerHandle) == kPeerHandleBytes, "PeerHandle layout");
+
+}  // namespace
+
+struct PeerMailbox {
+  unsigned char* mem = nullptr;
+  int nranks = 0;
+  size_t cap = 0;
+  PeerHandle handle;
+  ~PeerMailbox () { if (mem) (void) hipFree(mem); }
+  size_t bytes () const { return kMailboxHead + 2*static_cast<size_t>(nranks)*cap*sizeof(Real); }
+};
+
+namespace {
+
+// Why two parities are enough. Collective number e (the same on every rank: collectives are issued in the same order)
+// uses slots and counter e & 1 and waits for that counter to reach (e/2 + 1) P: P arrivals per collective of that
+// parity. A rank can only issue its put of collective e + 1 after its own wait of e, i.e. after EVERY rank's put of e
+// has landed in its mailbox; so when a put of e + 2 (the next user of parity e & 1) reaches my mailbox, its sender has
+// passed its wait of e + 1, hence my put of e + 1 ran, and that is ordered on my side (stream order, or the
+// cross-stream events) after my take of e: neither a slot of e nor the count of e can be disturbed by e + 2, and
+// arrivals of e + 1 go to the other counter.
+struct PeerFlagComm : public Comm {
+  std::shared_ptr<PeerMailbox> mine_;
+  int rank_, size_;
+  PeerTable tab_;
+  std::vector<void*> mapped_;  // other processes' mailboxes (to close)
+  uint64_t ncoll_ = 0;
+  CrossStreamOrder ord_;
+  PeerFlagComm (const std::shared_ptr<PeerMailbox>& mine, const void* handles, int rank, int size)
+    : mine_(mine), rank_(rank), size_(size) {
+    cedr_throw_if( ! mine || mine->nranks != size || rank < 0 || rank >= size, "peer flags: the mailbox was made for "
+                   << (mine ? mine->nranks : 0) << " ranks; asked for rank " << rank << " of " << size);
+    std::memset(&tab_, 0, sizeof(tab_));
+    const PeerHandle* const h = static_cast<const PeerHandle*>(handles);
+    for (int r = 0; r < size; ++r) {
+      PeerHandle hr;
+      std::memcpy(&hr, h + r, sizeof(hr));
+      cedr_throw_if(static_cast<int>(hr.nranks) != size || hr.cap != mine->cap,
+                    "peer flags: rank " << r << "'s mailbox has another shape than this rank's");
+      if (r == rank) {
+        cedr_throw_if(hr.ptr != reinterpret_cast<uint64_t>(mine->mem), "peer flags: handle " << r << " is not this rank's");
+        tab_.base[r] = mine->mem;
+      } else if (hr.pid == static_cast<int64_t>(getpid())) {
+        tab_.base[r] = reinterpret_cast<unsigned char*>(hr.ptr);  // ranks as threads of one process: the pointer itself
+      } else {
+        void* p = nullptr;
+        const hipError_t e = hipIpcOpenMemHandle(&p, hr.ipc, hipIpcMemLazyEnablePeerAccess);
+        cedr_throw_if(e != hipSuccess, "peer flags: hipIpcOpenMemHandle of rank " << r << "'s mailbox: "
+                      << hipGetErrorName(e));
+        mapped_.push_back(p);
+        tab_.base[r] = static_cast<unsigned char*>(p);
+      }
+    }
+  }
+  ~PeerFlagComm () override { for (void* p : mapped_) (void) hipIpcCloseMemHandle(p); }
+  int rank () const override { return rank_; }
+  int size () const override { return size_; }
+  int round (const Real* send, Real* recv, const size_t count, const int sum, const size_t block, hipStream_t s) {
+#ifdef __HIPCC__
+    const uint64_t e = ncoll_++;
+    const int parity = static_cast<int>(e & 1);
+    const size_t cap = mine_->cap, P = static_cast<size_t>(size_);
+    hipLaunchKernelGGL(peer_put_kernel, dim3(size_), dim3(256), 0, s, tab_, send, count,
+                       (parity*P + rank_)*cap, parity);
+    hipError_t h = hipGetLastError();
+    if (h != hipSuccess) return static_cast<int>(h);
+    h = hipStreamWaitValue64(s, reinterpret_cast<uint64_t*>(mine_->mem) + parity, (e/2 + 1)*P, hipStreamWaitValueGte,
+                             ~0ull);
+    if (h != hipSuccess) return static_cast<int>(h);
+    hipLaunchKernelGGL(peer_take_kernel, dim3(static_cast<unsigned>((count + 255)/256)), dim3(256), 0, s,
+                       mine_->mem, recv, count, parity*P*cap, cap, size_, sum, block);
+    return static_cast<int>(hipGetLastError());
+#else
+    (void) send; (void) recv; (void) count; (void) sum; (void) block; (void) s;
+    return -3;  // a host-only build of this file has no kernels
+#endif
+  }
+  int collective (const Real* send, Real* recv, const size_t count, const int sum, hipStream_t s) {
+    if (count == 0) return 0;
+    if (const int eo = ord_.before(s)) return eo;
+    int e = 0;
+    const size_t cap = mine_->cap;
+    // (longer than a slot: in pieces, each a round of its own; an all-gather's pieces land at their place in every block)
+    for (size_t o = 0; o < count && ! e; o += cap) e = round(send + o, recv + o, std::min(cap, count - o), sum, count, s);
+    const int ea = ord_.after(s);
+    return e ? e : ea;
+  }
+  int allgather (const Real* send, Real* recv, size_t count, hipStream_t s) override {
+    return collective(send, recv, count, 0, s);
+  }
+  int allreduce_sum (const Real* send, Real* recv, size_t count, hipStream_t s) override {
+    return collective(send, recv, count, 1, s);
+  }
+};
+
 // ------------------------------------------------------------------- rehearsal
 // Rank 0 of 'size' pretended ranks over a communicator of ONE real rank: what a single GPU can run of an N-GPU
 // job. A collective goes through the inner communicator for real (RcclComm of one rank: librccl's own enqueue
@@ -232,6 +383,42 @@ Parallel::Ptr make_parallel_rehearsal (const Parallel::Ptr& inner, int pretended
   cedr_throw_if( ! inner || inner->size() != 1, "a rehearsal communicator wraps a communicator of one rank");
   cedr_throw_if(pretended_size < 1, "pretended_size must be at least 1");
   return std::make_shared<Parallel>(std::make_shared<RehearsalComm>(inner->comm().ptr(), pretended_size));
+}
+
+std::shared_ptr<PeerMailbox> peer_mailbox_create (int size, size_t slot_doubles) {
+  cedr_throw_if(size < 1 || size > kPeerFlagsMaxRanks, "peer flags: 1 to " << kPeerFlagsMaxRanks << " ranks (one node)");
+  cedr_throw_if(slot_doubles < 1, "peer flags: empty slots");
+  int can = 0, dev = 0;
+  (void) hipGetDevice(&dev);
+  (void) hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, dev);
+  cedr_throw_if( ! can, "peer flags: this device has no hipStreamWaitValue64");
+  auto mb = std::make_shared<PeerMailbox>();
+  mb->nranks = size;
+  mb->cap = slot_doubles;
+  void* p = nullptr;
+  // fine-grained: stores from another GPU (and from another process on this one) are seen without a cache flush
+  hipError_t e = hipExtMallocWithFlags(&p, mb->bytes(), hipDeviceMallocFinegrained);
+  cedr_throw_if(e != hipSuccess, "peer flags: fine-grained allocation of " << mb->bytes() << " bytes: " << hipGetErrorName(e));
+  mb->mem = static_cast<unsigned char*>(p);
+  e = hipMemset(p, 0, mb->bytes());
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  cedr_throw_if(e != hipSuccess, "peer flags: clearing the mailbox: " << hipGetErrorName(e));
+  std::memset(&mb->handle, 0, sizeof(mb->handle));
+  e = hipIpcGetMemHandle(&mb->handle.ipc, p);
+  cedr_throw_if(e != hipSuccess, "peer flags: hipIpcGetMemHandle: " << hipGetErrorName(e));
+  mb->handle.pid = static_cast<int64_t>(getpid());
+  mb->handle.ptr = reinterpret_cast<uint64_t>(p);
+  mb->handle.nranks = static_cast<uint64_t>(size);
+  mb->handle.cap = slot_doubles;
+  return mb;
+}
+
+void peer_mailbox_handle (const PeerMailbox& mb, void* handle_96B) {
+  std::memcpy(handle_96B, &mb.handle, sizeof(mb.handle));
+}
+
+Parallel::Ptr make_parallel_peer_flags (const std::shared_ptr<PeerMailbox>& mine, const void* handles, int rank, int size) {
+  return std::make_shared<Parallel>(std::make_shared<PeerFlagComm>(mine, handles, rank, size));
 }
 
 Parallel::Ptr make_parallel () {

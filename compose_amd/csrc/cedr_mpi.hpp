@@ -94,6 +94,28 @@ Parallel::Ptr make_parallel_rccl (const void* unique_id_128B, int rank, int size
 // other ranks' blocks of an all-gather are copies of this rank's. For measurements and tests only.
 Parallel::Ptr make_parallel_rehearsal (const Parallel::Ptr& inner, int pretended_size);
 
+// PEER FLAGS (behind a knob; RCCL stays the default): a transport for the two KB-sized collectives of a step that
+// uses nothing but stream-ordered writes into the peers' memory -- no communicator library, no proxy thread, no
+// kernel that spins. Every rank owns a MAILBOX in fine-grained device memory (per source rank two payload slots, and
+// two arrival counters), exported with hipIpcGetMemHandle and mapped by every peer of the node over xGMI. A collective
+// is then, on the caller's stream: ONE launch that stores this rank's block into its slot of every mailbox and, after
+// a system-scope release, adds 1 to each mailbox's counter; ONE hipStreamWaitValue64 on this rank's own counter (all
+// P blocks have arrived); ONE launch that copies (all-gather) or sums in rank order (all-reduce: the same bits on
+// every rank) the P slots into recv. Slots and counters alternate between two parities by collective number, which
+// is what makes reuse safe without a second handshake (cedr_mpi.cpp). Replaces, for these two collectives, the
+// reference's per-level MPI messages (cedr_qlt.cpp:327-337,432-439) and MPI_Allreduce (cedr_caas.cpp:203-209), like
+// the RCCL backend; point-to-point rounds (exchange) are not offered, so plans that need them are refused.
+// Setup: every rank creates its mailbox, the launcher gathers the kPeerHandleBytes-byte handles of all ranks (rank
+// order) by any means it has, and make_parallel_peer_flags maps them. One node only; at most kPeerFlagsMaxRanks ranks.
+struct PeerMailbox;
+constexpr size_t kPeerHandleBytes = 96;
+constexpr int kPeerFlagsMaxRanks = 64;
+// 'slot_doubles': capacity of one payload slot; longer collectives run as several rounds.
+std::shared_ptr<PeerMailbox> peer_mailbox_create (int size, size_t slot_doubles = 4096);
+void peer_mailbox_handle (const PeerMailbox& mb, void* handle_96B);
+Parallel::Ptr make_parallel_peer_flags (const std::shared_ptr<PeerMailbox>& mine, const void* handles_in_rank_order,
+                                        int rank, int size);
+
 // Callback communicator: the host application supplies the two collectives.
 typedef int (*AllgatherFn) (void* user, const Real* send, Real* recv, size_t count, hipStream_t);
 typedef int (*AllreduceSumFn) (void* user, const Real* send, Real* recv, size_t count, hipStream_t);

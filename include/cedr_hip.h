@@ -291,6 +291,16 @@ void* cedr_parallel_create_rccl(const void* unique_id_128B, int rank, int size);
  * Parallel of one real rank (cedr_parallel_create_self or cedr_parallel_create_rccl(id, 0, 1)); collectives go
  * through `inner` for real, the other ranks' blocks of an all-gather are copies of this rank's. */
 void* cedr_parallel_create_rehearsal(void* inner_parallel, int pretended_size);
+/* Peer flags (behind a knob; RCCL stays the default): the two KB-sized collectives of a step as stream-ordered stores
+ * into the peers' IPC-mapped mailboxes + one hipStreamWaitValue64 per collective (compose_amd/csrc/cedr_mpi.hpp; replaces
+ * the same reference calls as the RCCL backend: cedr_qlt.cpp:327-337,432-439, cedr_caas.cpp:203-209). Every rank (one
+ * process per GPU of ONE node, at most 64) creates its mailbox -- `handle_out` receives CEDR_PEER_HANDLE_BYTES bytes --
+ * the launcher gathers all ranks' handles in rank order, and cedr_parallel_create_peer_flags maps them. The Parallel
+ * keeps the mailbox alive; cedr_peer_mailbox_destroy only drops the caller's reference. */
+#define CEDR_PEER_HANDLE_BYTES 96
+void* cedr_peer_mailbox_create(int size, size_t slot_doubles, void* handle_out);
+void cedr_peer_mailbox_destroy(void* mailbox);
+void* cedr_parallel_create_peer_flags(void* my_mailbox, const void* handles_in_rank_order, int rank, int size);
 /* Host-application transport (e.g. GPU-aware MPI). Buffers are device memory. */
 typedef int (*cedr_allgather_fn)(void* user, const double* send, double* recv, size_t count,
                                  cedr_stream_t stream);

@@ -1,0 +1,170 @@
+"""One RANK of a P-rank job over the product's peer-flag transport (cedr_mpi.hpp: PeerFlagComm), ranks as PROCESSES on
+the one GPU of the box (every process has its own hardware queues, so a rank's stream wait cannot hold up the launch of
+another rank that releases it -- ranks as threads of one process would share queues). Started P times by
+tests/test_gpu_peer_flags.py: usage  peer_flags_worker.py RANK SIZE DIR.
+
+The mailbox handles go from rank to rank through files in DIR. Every rank then runs, over ONE communicator: QLT through
+the all-gather (36 harness tracers, twice, two different sets of values in turn), CAAS's all-reduce, the BFB reducer
+(inputs scaled by powers of two from call to call, so a stale slot or an early wake-up shows),
+QLT and CAAS alternating on two streams -- and compares ITS cells bit for bit with the single-rank oracle (CAAS's own
+all-reduce: 1e-13 per tracer, and the same bits on every rank). A mismatch is recorded and reported at the end: a rank
+never leaves early, since the others would then wait for its blocks. Test infrastructure."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path[:0] = [os.path.dirname(HERE), HERE]
+
+import common  # noqa: E402
+import compose_amd as ca  # noqa: E402
+import oracle_lib as oracle  # noqa: E402
+import randomized as R  # noqa: E402
+
+
+def file_gather(d, name, rank, size, blob, timeout=120):
+    tmp = os.path.join(d, ".%s%d.tmp" % (name, rank))
+    with open(tmp, "wb") as f:
+        f.write(blob)
+    os.rename(tmp, os.path.join(d, "%s%d" % (name, rank)))
+    out, t0 = [], time.monotonic()
+    for r in range(size):
+        p = os.path.join(d, "%s%d" % (name, r))
+        while not os.path.exists(p):
+            if time.monotonic() - t0 > timeout:
+                raise SystemExit("rank %d: no %s from rank %d" % (rank, name, r))
+            time.sleep(0.01)
+        with open(p, "rb") as f:
+            out.append(f.read())
+    return out
+
+
+def main():
+    rank, size, d = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
+    slot = int(os.environ.get("PEER_SLOT_DOUBLES", "4096"))
+    bad = []
+    try:
+        mb, handle = ca.Parallel.peer_mailbox(size, slot)
+        err = b""
+    except ca.CedrError as e:
+        mb, handle, err = None, b"\0" * ca.Parallel.PEER_HANDLE_BYTES, str(e).encode()
+    errs = file_gather(d, "err", rank, size, err)
+    if any(errs):  # every rank sees the same list: all leave together, before any collective
+        print(json.dumps({"rank": rank, "setup_error": [e.decode() for e in errs]}))
+        return 2
+    handles = file_gather(d, "handle", rank, size, handle)
+    par = ca.Parallel.peer_flags(mb, handles, rank, size)
+    assert par.rank() == rank and par.size() == size
+    file_gather(d, "mapped", rank, size, b"1")  # nobody stores into a mailbox before everybody has mapped them all
+
+    # ---- QLT: all-gather of the ranks' subtree roots + the replicated top, twice two sets of values in turn
+    ncells = int(os.environ.get("PEER_NCELLS", "1531"))
+    trs = R.tracers_vector()
+    types = [t.problem_type for t in trs]
+    vs = [R.make_values(trs, ncells, seed=5 + s) for s in range(2)]
+    wants = [common.run_oracle_qlt(oracle, (False, False), ncells, 1, types, v, False) for v in vs]
+    tree = ca.Tree.make_1d(ncells, size, False, False)
+    q = ca.QLT(par, ncells, tree, False)
+    for t in types:
+        q.declare_tracer(t, 0)
+    q.end_tracer_declarations()
+    q.finish_setup()
+    g = q.get_owned_glblcells()
+    dv = [[ca.DeviceArray.from_numpy(np.ascontiguousarray(a)) for a in
+           (v.rhom[g], v.Qm[:, g], v.Qm_min[:, g], v.Qm_max[:, g], v.Qm_prev[:, g])] for v in vs]
+    od = ca.DeviceArray(len(types) * len(g))
+    for it in range(6):
+        k = it % 2
+        q.set_rhom(dv[k][0])
+        q.set_Qm(dv[k][1], dv[k][2], dv[k][3], dv[k][4])
+        q.run()
+        q.get_Qm(od)
+        ca.synchronize()
+        if not np.array_equal(od.numpy((len(types), len(g))), wants[k][:, g]):
+            bad.append("QLT pass %d" % it)
+
+    # ---- CAAS: its own all-reduce (sums in rank order)
+    ctrs = R.caas_tracers(trs)
+    ctypes_ = [t.problem_type for t in ctrs]
+    cv = R.make_values(ctrs, ncells, seed=77)
+    bounds = [ncells * r // size for r in range(size + 1)]
+    nl = [bounds[r + 1] - bounds[r] for r in range(size)]
+    cwant, _ = common.run_oracle_caas(oracle, nl, ctypes_, cv)
+    sl = slice(bounds[rank], bounds[rank + 1])
+    c = ca.CAAS(par, nl[rank])
+    for t in ctypes_:
+        c.declare_tracer(t, 0)
+    c.end_tracer_declarations()
+    c.finish_setup()
+    cd = [ca.DeviceArray.from_numpy(np.ascontiguousarray(a)) for a in
+          (cv.rhom[sl], cv.Qm[:, sl], cv.Qm_min[:, sl], cv.Qm_max[:, sl], cv.Qm_prev[:, sl])]
+    cod = ca.DeviceArray(len(ctypes_) * nl[rank])
+    caas_bits = None
+    for it in range(3):
+        c.set_rhom(cd[0])
+        c.set_Qm(cd[1], cd[2], cd[3], cd[4])
+        c.run()
+        c.get_Qm(cod)
+        ca.synchronize()
+        got = cod.numpy((len(ctypes_), nl[rank]))
+        if common.rel_per_tracer(got, cwant[:, sl]).max() > 1e-13:
+            bad.append("CAAS pass %d" % it)
+        if caas_bits is not None and not np.array_equal(got, caas_bits):
+            bad.append("CAAS pass %d differs from pass 0" % it)
+        caas_bits = got.copy()
+
+    # ---- the BFB reducer (all-gather of the ranks' roots): inputs scaled by 2^i from call to call
+    nleaf, nfield = ncells, 7
+    glob = np.random.default_rng(1234).random((nleaf, nfield))
+    bwant = oracle.bfb_allreduce(oracle.Tree.make_1d(nleaf, 1, False, False), nleaf, 1, nfield, True,
+                                 [np.ascontiguousarray(glob.T).ravel()])[0]
+    btree = ca.Tree.make_1d(nleaf, size, False, False)
+    ns = btree.analyze(nleaf, rank)
+    mine = np.array([ns["nodes"][i][1] for i in ns["levels"][0]["nodes"]], dtype=np.int64)
+    b = ca.BfbTreeAllReducer(par, btree, nleaf, nfield)
+    rd = ca.DeviceArray(nfield)
+    sends = [ca.DeviceArray.from_numpy(np.ascontiguousarray((glob[mine] * 2.0 ** i).T).ravel()) for i in range(4)]
+    for it in range(12):
+        i = it % 4
+        b.allreduce(sends[i], rd, True)
+        ca.synchronize()
+        if not np.array_equal(rd.numpy(), bwant * 2.0 ** i):
+            bad.append("BFB call %d" % it)
+
+    # ---- QLT and CAAS in turn on two streams, one communicator (the bench's default mode): the cross-stream ordering
+    import torch  # (only for the two streams)
+    ts = (torch.cuda.Stream(), torch.cuda.Stream())
+    q.set_stream(ts[0].cuda_stream)
+    c.set_stream(ts[1].cuda_stream)
+    for it in range(4):
+        k = it % 2
+        q.set_rhom(dv[k][0])
+        q.set_Qm(dv[k][1], dv[k][2], dv[k][3], dv[k][4])
+        c.set_rhom(cd[0])
+        c.set_Qm(cd[1], cd[2], cd[3], cd[4])
+        q.run()
+        c.run()
+        q.get_Qm(od)
+        c.get_Qm(cod)
+        ca.synchronize()
+        if not np.array_equal(od.numpy((len(types), len(g))), wants[k][:, g]):
+            bad.append("two streams: QLT pass %d" % it)
+        if not np.array_equal(cod.numpy((len(ctypes_), nl[rank])), caas_bits):
+            bad.append("two streams: CAAS pass %d" % it)
+
+    # every rank's CAAS result rows must be what the others computed from the same sums: compare the bits of the sums'
+    # effect through a digest of the global result
+    digs = file_gather(d, "caas", rank, size, caas_bits.tobytes())
+    allres = np.concatenate([np.frombuffer(x, dtype=np.float64).reshape(len(ctypes_), -1) for x in digs], axis=1)
+    if common.rel_per_tracer(allres, cwant).max() > 1e-13:
+        bad.append("CAAS global")
+    print(json.dumps({"rank": rank, "size": size, "ncells": ncells, "slot_doubles": slot, "bad": bad}))
+    file_gather(d, "done", rank, size, b"1")  # mailboxes stay mapped until every rank is through
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
