@@ -61,9 +61,12 @@ def parse():
     ap.add_argument("--cu-split", type=int, default=int(os.environ.get("CEDR_BENCH_CU_SPLIT", "0")), choices=[0, 1, 2, 3],
                     help="two-stream modes: CAAS::run on this many of every four groups of eight compute units, "
                          "QLT::run on the others (CU-masked streams); 0 = both on all of them")
-    ap.add_argument("--comm", choices=["rccl", "gloo"], default="rccl",
-                    help="data-path transport for N > 1: the library's RCCL communicator (default) or, "
-                         "for rehearsals on one GPU, host-staged torch.distributed/gloo callbacks")
+    ap.add_argument("--comm", choices=["rccl", "gloo", "peer-flags"], default="rccl",
+                    help="data-path transport for N > 1: the library's RCCL communicator (default); for rehearsals on "
+                         "one GPU, host-staged torch.distributed/gloo callbacks; or the library's peer-flag transport "
+                         "(stream-ordered stores into the peers' IPC-mapped mailboxes + one hipStreamWaitValue64 per "
+                         "collective, no communicator library; works with --same-gpu, ranks as processes; at --gpus 1 a "
+                         "communicator of ONE rank over the same code path, like --force-rccl)")
     ap.add_argument("--allow-host-fallback", action="store_true",
                     help="launcher mode only: if the RCCL run fails, start a FRESH set of rank processes "
                          "with --comm gloo (host-staged) and say so in the JSON line; without this flag a "
@@ -75,7 +78,7 @@ def parse():
                     help="QLT tracer problem types: all cst (BASELINE's metric) or the harness's six types "
                          "cst, st, ct, t, nn, cnn in turn (diagnostic)")
     ap.add_argument("--same-gpu", action="store_true",
-                    help="rehearsal: every rank uses GPU 0 (needs --comm gloo)")
+                    help="rehearsal: every rank uses GPU 0 (needs --comm gloo or --comm peer-flags)")
     ap.add_argument("--force-rccl", action="store_true",
                     help="--gpus 1 only: the CDRs get an RCCL communicator of ONE rank instead of the single-rank one, so "
                          "that every collective of a step really goes through librccl's enqueue path and, on two streams, "
@@ -89,6 +92,8 @@ def parse():
     a = ap.parse_args()
     if (a.force_rccl or a.pretend_ranks > 1) and a.gpus != 1:
         ap.error("--force-rccl and --pretend-ranks are rehearsals on ONE GPU (--gpus 1)")
+    if a.force_rccl and a.comm == "peer-flags":
+        ap.error("--force-rccl and --comm peer-flags are two different one-rank communicators")
     if a.pretend_ranks < 1:
         ap.error("--pretend-ranks must be at least 1")
     if a.check and a.types != "cst":
@@ -306,14 +311,29 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo", rank=rank, world_size=world)
-        if a.comm == "rccl":
-            # ONE communicator for both CDRs and ONE stream: the all-gather of QLT::run and the
-            # all-reduce of CAAS::run are enqueued in the same order on every rank.
-            uid = [ca.Parallel.rccl_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(uid, src=0)
+        if a.comm in ("rccl", "peer-flags"):
+            # ONE communicator for both CDRs: the all-gather of QLT::run and the all-reduce of CAAS::run are enqueued in
+            # the same order on every rank (and, on two streams, executed in that order: the library's events).
             err = None
+            if a.comm == "rccl":
+                uid = [ca.Parallel.rccl_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(uid, src=0)
+            else:
+                try:
+                    mailbox, handle = ca.Parallel.peer_mailbox(world)
+                except ca.CedrError as e:
+                    mailbox, handle, err = None, None, "CedrError: %s" % e
+                handles = [None] * world
+                dist.all_gather_object(handles, handle)
+                if any(h is None for h in handles):
+                    err = err or "a peer has no mailbox"
             try:
-                par = par2 = ca.Parallel.rccl(uid[0], rank, world)
+                if err:
+                    raise RuntimeError(err)
+                par = par2 = (ca.Parallel.rccl(uid[0], rank, world) if a.comm == "rccl" else
+                              ca.Parallel.peer_flags(mailbox, handles, rank, world))
+                if a.comm == "peer-flags":
+                    dist.barrier()  # nobody stores into a mailbox before every rank has mapped them all
                 qlt, caas = make_cdrs(par, par2)
                 # one untimed exchange through the communicator before anything is measured
                 z = torch.zeros((nt, qlt.nlclcells()), dtype=torch.float64, device=device)
@@ -330,23 +350,28 @@ def main():
                 # A transport that does not work is a failed run: never report host-staged
                 # numbers as multi-GPU results (a fresh `--comm gloo` run is the caller's choice).
                 if rank == 0:
-                    print("bench.py: RCCL transport failed: %s" % next(e for e in errs if e), file=sys.stderr)
+                    print("bench.py: %s transport failed: %s" % (a.comm, next(e for e in errs if e)), file=sys.stderr)
                 dist.destroy_process_group()
                 sys.exit(3)
-            transport = ("rccl: one communicator of %d ranks, %s, collectives in program order"
-                         % (world, "two streams (event ordered)" if a.overlap else "one stream"))
+            transport = ("%s: one communicator of %d ranks%s, %s, collectives in program order"
+                         % (a.comm, world, " (ALL ON GPU 0: a rehearsal)" if a.same_gpu else "",
+                            "two streams (event ordered)" if a.overlap else "one stream"))
         else:
             par = par2 = host_staged()
             qlt, caas = make_cdrs(par, par2)
             transport = "gloo-host-staged (rehearsal transport, not RCCL)"
     else:
-        inner = ca.Parallel.rccl(ca.Parallel.rccl_unique_id(), 0, 1) if a.force_rccl else ca.Parallel.self_()
+        if a.comm == "peer-flags":
+            mailbox, handle = ca.Parallel.peer_mailbox(1)
+            inner = ca.Parallel.peer_flags(mailbox, [handle], 0, 1)
+        else:
+            inner = ca.Parallel.rccl(ca.Parallel.rccl_unique_id(), 0, 1) if a.force_rccl else ca.Parallel.self_()
         par = par2 = ca.Parallel.rehearsal(inner, a.pretend_ranks) if a.pretend_ranks > 1 else inner
         keep.append((inner, None))
         qlt, caas = make_cdrs(par, par2)
-        if a.force_rccl or a.pretend_ranks > 1:
+        if a.force_rccl or a.pretend_ranks > 1 or a.comm == "peer-flags":
             transport = ("%s communicator of ONE rank%s, %s" %
-                         ("rccl" if a.force_rccl else "single-rank",
+                         ("rccl" if a.force_rccl else ("peer-flags" if a.comm == "peer-flags" else "single-rank"),
                           (", rehearsing rank 0 of %d (the other ranks' all-gather blocks are copies of this rank's)"
                            % a.pretend_ranks) if a.pretend_ranks > 1 else "",
                           "two streams (event ordered)" if a.overlap else "one stream"))

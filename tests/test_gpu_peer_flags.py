@@ -39,3 +39,37 @@ def test_peer_flags_ranks_as_processes_bitwise(gpu, size, env):
     """(slots of 64 doubles: QLT's all-gather and CAAS's all-reduce run in several rounds each)"""
     for r in run_ranks(size, env):
         assert r["bad"] == [], r
+
+
+ROOT = os.path.dirname(HERE)
+
+
+def _bench(args, timeout=600):
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True,
+                         timeout=timeout, cwd=ROOT)
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    return res, (json.loads(lines[-1]) if lines else None)
+
+
+@pytest.mark.parametrize("nranks,extra", [(2, []), (4, []), (2, ["--serial"]), (2, ["--caas-bfb", "4"])])
+def test_bench_over_peer_flags_ranks_on_one_gpu(gpu, nranks, extra):
+    """`bench.py --gpus N --same-gpu --comm peer-flags`: N rank processes on GPU 0, the step's two collectives over the
+    peer-flag transport, two streams by default; the results pass the checks and the line names the transport."""
+    res, d = _bench(["--gpus", str(nranks), "--comm", "peer-flags", "--same-gpu", "--steps", "3", "--warmup", "1",
+                     "--ncells", "48000", "--ntracers", "6", "--check", "--no-cpu-baseline"] + extra)
+    assert res.returncode == 0, res.stdout[-1500:] + res.stderr[-1500:]
+    assert d["n_gpus"] == nranks and d["check_ok"] is True
+    assert d["config"]["streams"] == (1 if "--serial" in extra else 2)
+    assert d["config"]["transport"].startswith("peer-flags: one communicator of %d ranks (ALL ON GPU 0" % nranks)
+    assert d["config"]["rccl_nranks"] == 0
+
+
+@pytest.mark.parametrize("extra", [[], ["--serial"]])
+def test_bench_rank_0_of_8_over_a_one_rank_peer_flag_communicator(gpu, extra):
+    """The one-GPU rehearsal of rank 0 of 8 (bench.py --pretend-ranks 8) with the peer-flag communicator of ONE rank
+    inside: put, stream wait and take are really enqueued for every collective."""
+    res, d = _bench(["--steps", "3", "--warmup", "1", "--ncells", "240000", "--ntracers", "6", "--check",
+                     "--no-cpu-baseline", "--comm", "peer-flags", "--pretend-ranks", "8"] + extra)
+    assert res.returncode == 0, res.stdout[-1500:] + res.stderr[-1500:]
+    assert d["n_gpus"] == 1 and d["check_ok"] is True
+    assert d["config"]["transport"].startswith("peer-flags communicator of ONE rank, rehearsing rank 0 of 8")
