@@ -5,8 +5,8 @@ tests/test_gpu_peer_flags.py: usage  peer_flags_worker.py RANK SIZE DIR.
 
 The mailbox handles go from rank to rank through files in DIR. Every rank then runs, over ONE communicator: QLT through
 the all-gather (36 harness tracers, twice, two different sets of values in turn), CAAS's all-reduce, the BFB reducer
-(inputs scaled by powers of two from call to call, so a stale slot or an early wake-up shows),
-QLT and CAAS alternating on two streams -- and compares ITS cells bit for bit with the single-rank oracle (CAAS's own
+(inputs scaled by powers of two from call to call, so a stale slot or an early wake-up shows; one call at a time and
+in bursts of 16 without host synchronisation), QLT and CAAS alternating on two streams -- and compares ITS cells bit for bit with the single-rank oracle (CAAS's own
 all-reduce: 1e-13 per tracer, and the same bits on every rank). A mismatch is recorded and reported at the end: a rank
 never leaves early, since the others would then wait for its blocks. Test infrastructure."""
 import json
@@ -135,6 +135,17 @@ def main():
         if not np.array_equal(rd.numpy(), bwant * 2.0 ** i):
             bad.append("BFB call %d" % it)
 
+    # ---- a burst: 16 reducer calls enqueued back to back, no host synchronisation in between (a fast rank runs as far
+    # ahead of a slow one as the transport lets it: the reuse of the two parities' slots is on its own)
+    rds = [ca.DeviceArray(nfield) for _ in range(16)]
+    for it in range(2 * rep):
+        for j, r_ in enumerate(rds):
+            b.allreduce(sends[(it + j) % 4], r_, True)
+        ca.synchronize()
+        for j, r_ in enumerate(rds):
+            if not np.array_equal(r_.numpy(), bwant * 2.0 ** ((it + j) % 4)):
+                bad.append("BFB burst %d call %d" % (it, j))
+
     # ---- QLT and CAAS in turn on two streams, one communicator (the bench's default mode): the cross-stream ordering
     import torch  # (only for the two streams)
     ts = (torch.cuda.Stream(), torch.cuda.Stream())
@@ -163,7 +174,7 @@ def main():
     if common.rel_per_tracer(allres, cwant).max() > 1e-13:
         bad.append("CAAS global")
     print(json.dumps({"rank": rank, "size": size, "ncells": ncells, "slot_doubles": slot, "repeat": rep,
-                      "collectives": 6 * rep + 3 + 12 * rep + 8 * rep, "bad": bad[:20], "nbad": len(bad)}))
+                      "collectives": 6 * rep + 3 + 12 * rep + 32 * rep + 8 * rep, "bad": bad[:20], "nbad": len(bad)}))
     file_gather(d, "done", rank, size, b"1")  # mailboxes stay mapped until every rank is through
     return 1 if bad else 0
 
