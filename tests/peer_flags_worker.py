@@ -46,6 +46,9 @@ def main():
     rank, size, d = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
     slot = int(os.environ.get("PEER_SLOT_DOUBLES", "4096"))
     rep = int(os.environ.get("PEER_REPEAT", "1"))  # soaks: every loop below this many times longer
+    if os.environ.get("PEER_DEVICE_PER_RANK") == "1":  # a box with several GPUs: rank r on GPU r (never run so far)
+        import torch
+        torch.cuda.set_device(rank)
     bad = []
     try:
         mb, handle = ca.Parallel.peer_mailbox(size, slot)
