@@ -327,13 +327,21 @@ def main():
                 dist.all_gather_object(handles, handle)
                 if any(h is None for h in handles):
                     err = err or "a peer has no mailbox"
+                if not err:
+                    try:
+                        par = par2 = ca.Parallel.peer_flags(mailbox, handles, rank, world)
+                    except ca.CedrError as e:
+                        err = "CedrError: %s" % e
+                # nobody stores into a mailbox before every rank has mapped them all (and a rank that could not leaves
+                # with the others: the gather is the barrier)
+                errs = [None] * world
+                dist.all_gather_object(errs, err)
+                err = next((e for e in errs if e), None)
             try:
                 if err:
                     raise RuntimeError(err)
-                par = par2 = (ca.Parallel.rccl(uid[0], rank, world) if a.comm == "rccl" else
-                              ca.Parallel.peer_flags(mailbox, handles, rank, world))
-                if a.comm == "peer-flags":
-                    dist.barrier()  # nobody stores into a mailbox before every rank has mapped them all
+                if a.comm == "rccl":
+                    par = par2 = ca.Parallel.rccl(uid[0], rank, world)
                 qlt, caas = make_cdrs(par, par2)
                 # one untimed exchange through the communicator before anything is measured
                 z = torch.zeros((nt, qlt.nlclcells()), dtype=torch.float64, device=device)
@@ -350,7 +358,8 @@ def main():
                 # A transport that does not work is a failed run: never report host-staged
                 # numbers as multi-GPU results (a fresh `--comm gloo` run is the caller's choice).
                 if rank == 0:
-                    print("bench.py: %s transport failed: %s" % (a.comm, next(e for e in errs if e)), file=sys.stderr)
+                    print("bench.py: %s transport failed: %s" % ("RCCL" if a.comm == "rccl" else a.comm,
+                                                                 next(e for e in errs if e)), file=sys.stderr)
                 dist.destroy_process_group()
                 sys.exit(3)
             transport = ("%s: one communicator of %d ranks%s, %s, collectives in program order"

@@ -256,6 +256,7 @@ struct PeerMailbox {
   unsigned char* mem = nullptr;
   int nranks = 0;
   size_t cap = 0;
+  bool taken = false;  // a mailbox serves ONE communicator: its counters count that communicator's collectives
   PeerHandle handle;
   ~PeerMailbox () { if (mem) (void) hipFree(mem); }
   size_t bytes () const { return kMailboxHead + 2*static_cast<size_t>(nranks)*cap*sizeof(Real); }
@@ -274,13 +275,17 @@ struct PeerFlagComm : public Comm {
   std::shared_ptr<PeerMailbox> mine_;
   int rank_, size_;
   PeerTable tab_;
-  std::vector<void*> mapped_;  // other processes' mailboxes (to close)
+  struct Mapped {  // other processes' mailboxes; unmapped also when the constructor throws half way
+    std::vector<void*> p;
+    ~Mapped () { for (void* q : p) (void) hipIpcCloseMemHandle(q); }
+  } mapped_;
   uint64_t ncoll_ = 0;
   CrossStreamOrder ord_;
   PeerFlagComm (const std::shared_ptr<PeerMailbox>& mine, const void* handles, int rank, int size)
     : mine_(mine), rank_(rank), size_(size) {
     cedr_throw_if( ! mine || mine->nranks != size || rank < 0 || rank >= size, "peer flags: the mailbox was made for "
                    << (mine ? mine->nranks : 0) << " ranks; asked for rank " << rank << " of " << size);
+    cedr_throw_if(mine->taken, "peer flags: this mailbox already serves a communicator");
     std::memset(&tab_, 0, sizeof(tab_));
     const PeerHandle* const h = static_cast<const PeerHandle*>(handles);
     for (int r = 0; r < size; ++r) {
@@ -298,12 +303,12 @@ struct PeerFlagComm : public Comm {
         const hipError_t e = hipIpcOpenMemHandle(&p, hr.ipc, hipIpcMemLazyEnablePeerAccess);
         cedr_throw_if(e != hipSuccess, "peer flags: hipIpcOpenMemHandle of rank " << r << "'s mailbox: "
                       << hipGetErrorName(e));
-        mapped_.push_back(p);
+        mapped_.p.push_back(p);
         tab_.base[r] = static_cast<unsigned char*>(p);
       }
     }
+    mine->taken = true;
   }
-  ~PeerFlagComm () override { for (void* p : mapped_) (void) hipIpcCloseMemHandle(p); }
   int rank () const override { return rank_; }
   int size () const override { return size_; }
   int round (const Real* send, Real* recv, const size_t count, const int sum, const size_t block, hipStream_t s) {
