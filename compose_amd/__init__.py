@@ -76,6 +76,8 @@ _SIGS = {
     "cedr_parallel_create_callbacks_p2p": (_vp, [C.c_int, C.c_int, ALLGATHER_FN, ALLREDUCE_FN, EXCHANGE_FN, _vp]),
     "cedr_parallel_exchange": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
                                          C.POINTER(C.c_int), _vp]),
+    "cedr_parallel_allgather": (C.c_int, [_vp, _vp, _vp, C.c_size_t, _vp]),
+    "cedr_parallel_allreduce_sum": (C.c_int, [_vp, _vp, _vp, C.c_size_t, _vp]),
     "cedr_parallel_rank": (C.c_int, [_vp]),
     "cedr_parallel_size": (C.c_int, [_vp]),
     "cedr_parallel_free": (None, [_vp]),
@@ -508,6 +510,13 @@ class Parallel:
         counts = (C.c_size_t * n)(*[o[2] for o in ops])
         sends = (C.c_int * n)(*[int(o[3]) for o in ops])
         return lib().cedr_parallel_exchange(self.h, n, peers, bufs, counts, sends, stream)
+
+    def allgather(self, send, recv, count, stream=None):
+        """recv[r*count:(r+1)*count] = rank r's send[:count] (DeviceArrays or device pointers), enqueued on stream."""
+        _chk(lib().cedr_parallel_allgather(self.h, _ptr(send), _ptr(recv), int(count), stream), "allgather")
+
+    def allreduce_sum(self, send, recv, count, stream=None):
+        _chk(lib().cedr_parallel_allreduce_sum(self.h, _ptr(send), _ptr(recv), int(count), stream), "allreduce_sum")
 
     def rank(self):
         return lib().cedr_parallel_rank(self.h)

@@ -99,6 +99,16 @@ int cedr_parallel_exchange (void* p, int nops, const int* peers, double* const* 
   return static_cast<ParallelBox*>(p)->p->comm()->exchange(ops.data(), nops, static_cast<hipStream_t>(stream));
   CEDR_CATCH(-1)
 }
+int cedr_parallel_allgather (void* p, const double* send, double* recv, size_t count, cedr_stream_t stream) {
+  CEDR_TRY
+  return static_cast<ParallelBox*>(p)->p->comm()->allgather(send, recv, count, static_cast<hipStream_t>(stream));
+  CEDR_CATCH(-1)
+}
+int cedr_parallel_allreduce_sum (void* p, const double* send, double* recv, size_t count, cedr_stream_t stream) {
+  CEDR_TRY
+  return static_cast<ParallelBox*>(p)->p->comm()->allreduce_sum(send, recv, count, static_cast<hipStream_t>(stream));
+  CEDR_CATCH(-1)
+}
 int cedr_parallel_rank (void* p) { return static_cast<ParallelBox*>(p)->p->rank(); }
 int cedr_parallel_size (void* p) { return static_cast<ParallelBox*>(p)->p->size(); }
 void cedr_parallel_free (void* p) { delete static_cast<ParallelBox*>(p); }

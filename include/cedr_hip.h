@@ -320,6 +320,11 @@ void* cedr_parallel_create_callbacks_p2p(int rank, int size, cedr_allgather_fn a
  * use between tree levels); arguments as cedr_exchange_fn. */
 int cedr_parallel_exchange(void* p, int nops, const int* peers, double* const* bufs, const size_t* counts,
                            const int* sends, cedr_stream_t stream);
+/* The two collectives of a Parallel's transport, enqueued on `stream` over device buffers (what QLT::run / CAAS::run /
+ * the BFB reducer call between their launches; for transport tests and latency measurements): recv[r*count ..] = rank r's
+ * send[0 .. count) / recv[i] = sum over ranks of send[i]. */
+int cedr_parallel_allgather(void* p, const double* send, double* recv, size_t count, cedr_stream_t stream);
+int cedr_parallel_allreduce_sum(void* p, const double* send, double* recv, size_t count, cedr_stream_t stream);
 int cedr_parallel_rank(void* p);
 int cedr_parallel_size(void* p);
 void cedr_parallel_free(void* p);
