@@ -68,6 +68,62 @@ __global__ void peer_take_kernel (const unsigned char* __restrict__ mb, Real* __
   }
   if (sum) recv[i] = acc;
 }
+// The three operations as ONE launch (CEDR_HIP_PEER_WAIT=kernel): workgroup r stores this rank's block into rank r's
+// mailbox and announces it (nothing to itself: its own block is read from `send`), then waits IN THE KERNEL for the
+// P - 1 other ranks' arrivals in this rank's mailbox, then takes -- source r's block (all-gather), or the r-th share of
+// the elements summed over the ranks in rank order (all-reduce; the same expression as peer_take_kernel's). The wait
+// depends on the OTHER ranks' launches only, never on a workgroup of this launch; it gives up after ~2^24 polls (a few
+// seconds: a peer that never arrives), raises the mailbox's error word and fills recv with NaN, so that every wave ends.
+__global__ void peer_xchg_kernel (const PeerTable t, const int me, const int nranks, const Real* __restrict__ send,
+                                  Real* __restrict__ recv, const size_t count, const size_t cap, const int parity,
+                                  const unsigned long long target, const int sum, const size_t block) {
+  const int r = blockIdx.x;
+  unsigned char* const mine = t.base[me];
+  const unsigned long long* const src = reinterpret_cast<const unsigned long long*>(send);
+  const size_t P = static_cast<size_t>(nranks);
+  if (r != me) {
+    unsigned char* const mb = t.base[r];
+    unsigned long long* const dst = reinterpret_cast<unsigned long long*>(mb + kMailboxHead) + (parity*P + me)*cap;
+    for (size_t i = threadIdx.x; i < count; i += blockDim.x)
+      __hip_atomic_store(dst + i, src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0)
+      __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(mb) + parity, 1ull, __ATOMIC_RELEASE,
+                             __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  __shared__ int gave_up;
+  if (threadIdx.x == 0) {
+    gave_up = 0;
+    const unsigned long long* const ctr = reinterpret_cast<const unsigned long long*>(mine) + parity;
+    unsigned polls = 0;
+    while (__hip_atomic_load(ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < target) {
+      if (++polls > (1u << 24)) { gave_up = 1; break; }
+      __builtin_amdgcn_s_sleep(8);
+    }
+    if (gave_up)
+      __hip_atomic_store(reinterpret_cast<unsigned long long*>(mine) + 2, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  __syncthreads();
+  __threadfence_system();
+  const bool bad = gave_up != 0;
+  const unsigned long long* const slots = reinterpret_cast<const unsigned long long*>(mine + kMailboxHead) + parity*P*cap;
+  auto value = [&] (const int q, const size_t i) -> Real {
+    const unsigned long long bits = q == me ? src[i] :
+      __hip_atomic_load(slots + static_cast<size_t>(q)*cap + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return bad ? __longlong_as_double(0x7ff8000000000000ll) : __longlong_as_double(static_cast<long long>(bits));
+  };
+  if ( ! sum) {
+    for (size_t i = threadIdx.x; i < count; i += blockDim.x) recv[static_cast<size_t>(r)*block + i] = value(r, i);
+  } else {
+    const size_t lo = count*static_cast<size_t>(r)/P, hi = count*(static_cast<size_t>(r) + 1)/P;
+    for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+      Real acc = value(0, i);
+      for (int q = 1; q < nranks; ++q) acc = acc + value(q, i);
+      recv[i] = acc;
+    }
+  }
+}
 #endif
 
 // Collectives of ONE communicator must execute in the same order on every rank. Callers issue
@@ -281,6 +337,10 @@ struct PeerFlagComm : public Comm {
   } mapped_;
   uint64_t ncoll_ = 0;
   CrossStreamOrder ord_;
+  // CEDR_HIP_PEER_WAIT=kernel: put, wait and take as ONE launch that waits for the arrivals itself (peer_xchg_kernel)
+  // instead of two launches around a hipStreamWaitValue64. The same on every rank of a communicator: the two forms count
+  // arrivals differently (with / without the rank's own block).
+  bool in_kernel_ = false;
   PeerFlagComm (const std::shared_ptr<PeerMailbox>& mine, const void* handles, int rank, int size)
     : mine_(mine), rank_(rank), size_(size) {
     cedr_throw_if( ! mine || mine->nranks != size || rank < 0 || rank >= size, "peer flags: the mailbox was made for "
@@ -308,7 +368,9 @@ struct PeerFlagComm : public Comm {
       }
     }
     mine->taken = true;
+    if (const char* e = std::getenv("CEDR_HIP_PEER_WAIT")) in_kernel_ = std::strcmp(e, "kernel") == 0;
   }
+  bool overlap (const Real* a, const Real* b, const size_t n) const { return a < b + n && b < a + n; }
   int rank () const override { return rank_; }
   int size () const override { return size_; }
   int round (const Real* send, Real* recv, const size_t count, const int sum, const size_t block, hipStream_t s) {
@@ -316,6 +378,11 @@ struct PeerFlagComm : public Comm {
     const uint64_t e = ncoll_++;
     const int parity = static_cast<int>(e & 1);
     const size_t cap = mine_->cap, P = static_cast<size_t>(size_);
+    if (in_kernel_) {
+      hipLaunchKernelGGL(peer_xchg_kernel, dim3(size_), dim3(256), 0, s, tab_, rank_, size_, send, recv, count, cap, parity,
+                         static_cast<unsigned long long>((e/2 + 1)*(P - 1)), sum, block);
+      return static_cast<int>(hipGetLastError());
+    }
     hipLaunchKernelGGL(peer_put_kernel, dim3(size_), dim3(256), 0, s, tab_, send, count,
                        (parity*P + rank_)*cap, parity);
     hipError_t h = hipGetLastError();
@@ -333,6 +400,8 @@ struct PeerFlagComm : public Comm {
   }
   int collective (const Real* send, Real* recv, const size_t count, const int sum, hipStream_t s) {
     if (count == 0) return 0;
+    // (the one-launch form reads `send` while other workgroups may already write `recv`)
+    if (in_kernel_ && overlap(send, recv, sum ? count : count*static_cast<size_t>(size_))) return -5;
     if (const int eo = ord_.before(s)) return eo;
     int e = 0;
     const size_t cap = mine_->cap;

@@ -33,8 +33,12 @@ def run_ranks(size, env=None, timeout=420):
         return res
 
 
+ONE = {"CEDR_HIP_PEER_WAIT": "kernel"}  # put, wait and take as one launch that waits for the arrivals itself
+
+
 @pytest.mark.parametrize("size,env", [(1, {}), (2, {}), (4, {}), (3, {"PEER_NCELLS": "700"}),
-                                      (2, {"PEER_SLOT_DOUBLES": "64"})])
+                                      (2, {"PEER_SLOT_DOUBLES": "64"}),
+                                      (1, ONE), (2, ONE), (4, ONE), (3, dict(ONE, PEER_SLOT_DOUBLES="100", PEER_NCELLS="700"))])
 def test_peer_flags_ranks_as_processes_bitwise(gpu, size, env):
     """(slots of 64 doubles: QLT's all-gather and CAAS's all-reduce run in several rounds each)"""
     for r in run_ranks(size, env):
