@@ -370,7 +370,7 @@ struct PeerFlagComm : public Comm {
     mine->taken = true;
     if (const char* e = std::getenv("CEDR_HIP_PEER_WAIT")) in_kernel_ = std::strcmp(e, "kernel") == 0;
   }
-  bool overlap (const Real* a, const Real* b, const size_t n) const { return a < b + n && b < a + n; }
+  static bool overlap (const Real* a, const size_t na, const Real* b, const size_t nb) { return a < b + nb && b < a + na; }
   int rank () const override { return rank_; }
   int size () const override { return size_; }
   int round (const Real* send, Real* recv, const size_t count, const int sum, const size_t block, hipStream_t s) {
@@ -401,7 +401,7 @@ struct PeerFlagComm : public Comm {
   int collective (const Real* send, Real* recv, const size_t count, const int sum, hipStream_t s) {
     if (count == 0) return 0;
     // (the one-launch form reads `send` while other workgroups may already write `recv`)
-    if (in_kernel_ && overlap(send, recv, sum ? count : count*static_cast<size_t>(size_))) return -5;
+    if (in_kernel_ && overlap(send, count, recv, sum ? count : count*static_cast<size_t>(size_))) return -5;
     if (const int eo = ord_.before(s)) return eo;
     int e = 0;
     const size_t cap = mine_->cap;
