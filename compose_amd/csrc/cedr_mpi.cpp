@@ -68,15 +68,17 @@ __global__ void peer_take_kernel (const unsigned char* __restrict__ mb, Real* __
   }
   if (sum) recv[i] = acc;
 }
-// The three operations as ONE launch (CEDR_HIP_PEER_WAIT=kernel): workgroup r stores this rank's block into rank r's
+// The three operations as ONE launch (the default form; CEDR_HIP_PEER_WAIT=stream: the three above): workgroup r stores this rank's block into rank r's
 // mailbox and announces it (nothing to itself: its own block is read from `send`), then waits IN THE KERNEL for the
 // P - 1 other ranks' arrivals in this rank's mailbox, then takes -- source r's block (all-gather), or the r-th share of
 // the elements summed over the ranks in rank order (all-reduce; the same expression as peer_take_kernel's). The wait
-// depends on the OTHER ranks' launches only, never on a workgroup of this launch; it gives up after ~2^24 polls (a few
-// seconds: a peer that never arrives), raises the mailbox's error word and fills recv with NaN, so that every wave ends.
+// depends on the OTHER ranks' launches only, never on a workgroup of this launch; it gives up after `max_polls` polls of
+// about a microsecond (2^28 by default, minutes: a peer that never arrives; CEDR_HIP_PEER_GIVE_UP_LOG2), raises the
+// mailbox's error word and fills recv with NaN, so that every wave ends whatever the peers do.
 __global__ void peer_xchg_kernel (const PeerTable t, const int me, const int nranks, const Real* __restrict__ send,
                                   Real* __restrict__ recv, const size_t count, const size_t cap, const int parity,
-                                  const unsigned long long target, const int sum, const size_t block) {
+                                  const unsigned long long target, const int sum, const size_t block,
+                                  const unsigned long long max_polls) {
   const int r = blockIdx.x;
   unsigned char* const mine = t.base[me];
   const unsigned long long* const src = reinterpret_cast<const unsigned long long*>(send);
@@ -96,9 +98,9 @@ __global__ void peer_xchg_kernel (const PeerTable t, const int me, const int nra
   if (threadIdx.x == 0) {
     gave_up = 0;
     const unsigned long long* const ctr = reinterpret_cast<const unsigned long long*>(mine) + parity;
-    unsigned polls = 0;
+    unsigned long long polls = 0;
     while (__hip_atomic_load(ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < target) {
-      if (++polls > (1u << 24)) { gave_up = 1; break; }
+      if (++polls > max_polls) { gave_up = 1; break; }
       __builtin_amdgcn_s_sleep(8);
     }
     if (gave_up)
@@ -337,10 +339,12 @@ struct PeerFlagComm : public Comm {
   } mapped_;
   uint64_t ncoll_ = 0;
   CrossStreamOrder ord_;
-  // CEDR_HIP_PEER_WAIT=kernel: put, wait and take as ONE launch that waits for the arrivals itself (peer_xchg_kernel)
-  // instead of two launches around a hipStreamWaitValue64. The same on every rank of a communicator: the two forms count
-  // arrivals differently (with / without the rank's own block).
-  bool in_kernel_ = false;
+  // Put, wait and take as ONE launch that waits for the arrivals itself (peer_xchg_kernel; the default: 9 us per
+  // collective back to back between two processes against 15 us, profiles/r05_peer_flags.txt), or
+  // CEDR_HIP_PEER_WAIT=stream: two launches around a hipStreamWaitValue64. The same on every rank of a communicator: the
+  // two forms count arrivals differently (without / with the rank's own block).
+  bool in_kernel_ = true;
+  unsigned long long max_polls_ = 1ull << 28;
   PeerFlagComm (const std::shared_ptr<PeerMailbox>& mine, const void* handles, int rank, int size)
     : mine_(mine), rank_(rank), size_(size) {
     cedr_throw_if( ! mine || mine->nranks != size || rank < 0 || rank >= size, "peer flags: the mailbox was made for "
@@ -368,7 +372,8 @@ struct PeerFlagComm : public Comm {
       }
     }
     mine->taken = true;
-    if (const char* e = std::getenv("CEDR_HIP_PEER_WAIT")) in_kernel_ = std::strcmp(e, "kernel") == 0;
+    if (const char* e = std::getenv("CEDR_HIP_PEER_WAIT")) in_kernel_ = std::strcmp(e, "stream") != 0;
+    if (const char* e = std::getenv("CEDR_HIP_PEER_GIVE_UP_LOG2")) max_polls_ = 1ull << std::max(10, std::min(40, std::atoi(e)));
   }
   static bool overlap (const Real* a, const size_t na, const Real* b, const size_t nb) { return a < b + nb && b < a + na; }
   int rank () const override { return rank_; }
@@ -380,7 +385,7 @@ struct PeerFlagComm : public Comm {
     const size_t cap = mine_->cap, P = static_cast<size_t>(size_);
     if (in_kernel_) {
       hipLaunchKernelGGL(peer_xchg_kernel, dim3(size_), dim3(256), 0, s, tab_, rank_, size_, send, recv, count, cap, parity,
-                         static_cast<unsigned long long>((e/2 + 1)*(P - 1)), sum, block);
+                         static_cast<unsigned long long>((e/2 + 1)*(P - 1)), sum, block, max_polls_);
       return static_cast<int>(hipGetLastError());
     }
     hipLaunchKernelGGL(peer_put_kernel, dim3(size_), dim3(256), 0, s, tab_, send, count,

@@ -64,6 +64,23 @@ def main():
     assert par.rank() == rank and par.size() == size
     file_gather(d, "mapped", rank, size, b"1")  # nobody stores into a mailbox before everybody has mapped them all
 
+    if os.environ.get("PEER_MODE") == "giveup":
+        # A peer that never arrives: rank 0's one-launch collective gives up after CEDR_HIP_PEER_GIVE_UP_LOG2 polls,
+        # every wave ends, and the result is NaN (never a plausible number); the other ranks only keep their mailboxes.
+        if rank == 0:
+            sd = ca.DeviceArray.from_numpy(np.arange(8, dtype=np.float64))
+            rd_ = ca.DeviceArray.from_numpy(np.zeros(8))
+            t0 = time.monotonic()
+            par.allreduce_sum(sd, rd_, 8)
+            ca.synchronize()
+            got = rd_.numpy()
+            print(json.dumps({"rank": 0, "gave_up_nan": bool(np.isnan(got).all()), "seconds": time.monotonic() - t0,
+                              "bad": [] if np.isnan(got).all() else ["a result without the peer"]}))
+        else:
+            print(json.dumps({"rank": rank, "bad": []}))
+        file_gather(d, "done", rank, size, b"1")
+        return 0
+
     # ---- QLT: all-gather of the ranks' subtree roots + the replicated top, twice two sets of values in turn
     ncells = int(os.environ.get("PEER_NCELLS", "1531"))
     trs = R.tracers_vector()
