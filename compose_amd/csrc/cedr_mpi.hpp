@@ -98,10 +98,12 @@ Parallel::Ptr make_parallel_rehearsal (const Parallel::Ptr& inner, int pretended
 // uses nothing but stream-ordered writes into the peers' memory -- no communicator library, no proxy thread, no
 // kernel that spins. Every rank owns a MAILBOX in fine-grained device memory (per source rank two payload slots, and
 // two arrival counters), exported with hipIpcGetMemHandle and mapped by every peer of the node over xGMI. A collective
-// is then, on the caller's stream: ONE launch that stores this rank's block into its slot of every mailbox and, after
-// a system-scope release, adds 1 to each mailbox's counter; ONE hipStreamWaitValue64 on this rank's own counter (all
-// P blocks have arrived); ONE launch that copies (all-gather) or sums in rank order (all-reduce: the same bits on
-// every rank) the P slots into recv. Slots and counters alternate between two parities by collective number, which
+// is then, on the caller's stream: stores of this rank's block into its slot of every mailbox and, after a system-scope
+// release, an add of 1 on each mailbox's counter; a wait until this rank's own counter says that all blocks have
+// arrived; a copy (all-gather) or a sum in rank order (all-reduce: the same bits on every rank) of the P slots into
+// recv -- as ONE launch that waits in the kernel, bounded (the default), or as a put launch, ONE hipStreamWaitValue64
+// and a take launch (CEDR_HIP_PEER_WAIT=stream; the same choice on every rank). In the one-launch form send and recv
+// must not overlap. Slots and counters alternate between two parities by collective number, which
 // is what makes reuse safe without a second handshake (cedr_mpi.cpp). Replaces, for these two collectives, the
 // reference's per-level MPI messages (cedr_qlt.cpp:327-337,432-439) and MPI_Allreduce (cedr_caas.cpp:203-209), like
 // the RCCL backend; point-to-point rounds (exchange) are not offered, so plans that need them are refused.
