@@ -328,7 +328,9 @@ namespace {
 // has landed in its mailbox; so when a put of e + 2 (the next user of parity e & 1) reaches my mailbox, its sender has
 // passed its wait of e + 1, hence my put of e + 1 ran, and that is ordered on my side (stream order, or the
 // cross-stream events) after my take of e: neither a slot of e nor the count of e can be disturbed by e + 2, and
-// arrivals of e + 1 go to the other counter.
+// arrivals of e + 1 go to the other counter. The one-launch form counts P - 1 arrivals per collective (a rank sends
+// nothing to itself) and puts at the START of its launch of e + 1, which its stream begins after its launch of e --
+// wait and take included -- has ended: the same argument.
 struct PeerFlagComm : public Comm {
   std::shared_ptr<PeerMailbox> mine_;
   int rank_, size_;
