@@ -7,7 +7,8 @@ O=gpurun_out/r05pf
 mkdir -p $O
 {
 echo "# kernels_sha256 $(python3 -c 'import compose_amd as c; print(c.kernels_sha256())')"
-for cfg in "4 100 4096 1531" "2 100 64 700" "3 100 4096 20011" "4 200 128 333"; do
+IFS=';' read -ra CASES <<< "${PEER_SOAK_CASES:-4 100 4096 1531;2 100 64 700;3 100 4096 20011;4 200 128 333}"
+for cfg in "${CASES[@]}"; do
   set -- $cfg
   D=$(mktemp -d /tmp/pfsXXXXXX)
   pids=""
