@@ -119,7 +119,21 @@ int main (int argc, char** argv) {
       HIP_OK(hipDeviceSynchronize());
       return out.get((size_t) nt*g.size());
     };
-    const auto pm = cedr::mpi::make_parallel(MPI_COMM_WORLD);
+    // --peer-flags: the ranks' communicator is the library's peer-flag transport, set up as INTEGRATION.md shows: the
+    // mailbox handles go round with one MPI_Allgather, after which MPI carries nothing of the CDRs' data.
+    const bool peer = argc > 1 && ! std::strcmp(argv[1], "--peer-flags");
+    cedr::mpi::Parallel::Ptr pm;
+    if (peer) {
+      auto mb = cedr::mpi::peer_mailbox_create(size);
+      char mine[cedr::mpi::kPeerHandleBytes];
+      std::vector<char> all((size_t) size*cedr::mpi::kPeerHandleBytes);
+      cedr::mpi::peer_mailbox_handle(*mb, mine);
+      MPI_Allgather(mine, (int) sizeof(mine), MPI_BYTE, all.data(), (int) sizeof(mine), MPI_BYTE, MPI_COMM_WORLD);
+      pm = cedr::mpi::make_parallel_peer_flags(mb, all.data(), rank, size);
+      MPI_Barrier(MPI_COMM_WORLD);  // every rank has mapped every mailbox before the first run()
+    } else {
+      pm = cedr::mpi::make_parallel(MPI_COMM_WORLD);
+    }
     const auto ps = cedr::mpi::make_parallel();
     if (pm->size() != size || pm->rank() != rank) ++nerr;
     std::vector<cedr::Long> g1, gm;
@@ -132,6 +146,12 @@ int main (int argc, char** argv) {
     if (nq) { std::printf("rank %d FAIL QLT over MPI differs from the single-rank run in %d values\n", rank, nq); nerr += nq; }
     for (int form = 1; form <= 2; ++form) {
       std::vector<cedr::Long> gp;
+      if (peer) {  // no point-to-point rounds in this transport: a partial tree is refused when the QLT is constructed
+        bool refused = false;
+        try { run_qlt(pm, gp, form); } catch (const std::exception&) { refused = true; }
+        if ( ! refused && size > 1) { std::printf("rank %d FAIL a partial tree was not refused over peer flags\n", rank); ++nerr; }
+        continue;
+      }
       const std::vector<Real> part = run_qlt(pm, gp, form);
       int np = gp.size() == gm.size() ? 0 : 1;
       for (int t = 0; t < nt && ! np; ++t) for (size_t i = 0; i < gp.size(); ++i)

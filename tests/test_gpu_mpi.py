@@ -22,3 +22,17 @@ def test_cdrs_over_mpi(gpu, tmp_path, nranks):
                          env=mpi_env(tmp_path))
     assert res.returncode == 0 and "CEDR_MPI_OK %d ranks" % nranks in res.stdout, \
         res.stdout[-2000:] + res.stderr[-2000:]
+
+
+@pytest.mark.skipif(not os.path.exists(MPIEXEC), reason="no MPI in this image")
+@pytest.mark.parametrize("nranks", [2, 4])
+def test_cdrs_over_peer_flags_set_up_through_mpi(gpu, tmp_path, nranks):
+    """The same C++ caller with `--peer-flags`: MPI only gathers the 96-byte mailbox handles; QLT, CAAS
+    and the BFB reducer then run over cedr::mpi::make_parallel_peer_flags, bitwise against the single-rank run; partial
+    trees are refused at construction (the transport has no point-to-point rounds)."""
+    exe = os.path.join(ROOT, "tests", "cpp", "cedr_test_mpi")
+    subprocess.check_call(["make", "-s", "-C", os.path.dirname(exe), "cedr_test_mpi"])
+    res = subprocess.run([MPIEXEC, "-np", str(nranks), exe, "--peer-flags"], capture_output=True, text=True, timeout=600,
+                         env=mpi_env(tmp_path))
+    assert res.returncode == 0 and "CEDR_MPI_OK %d ranks" % nranks in res.stdout, \
+        res.stdout[-2000:] + res.stderr[-2000:]
