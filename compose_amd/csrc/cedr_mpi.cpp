@@ -68,6 +68,78 @@ __global__ void peer_take_kernel (const unsigned char* __restrict__ mb, Real* __
   }
   if (sum) recv[i] = acc;
 }
+// Point-to-point rounds (Comm::exchange) over the same mailboxes: behind the collectives' region every mailbox has, per
+// peer and parity, a message slot, a FLAG (number of the message in the slot, + 1) written by the sender, and an ACK
+// (number of my message the peer has consumed, + 1) written back by the receiver into the SENDER's mailbox. Messages of
+// one ordered pair are numbered 0, 1, 2, ... (a round has at most one per pair and direction, a longer one goes in pieces)
+// and use parity = number & 1; a sender reuses a slot only after the ack of the message two before. One launch per
+// round, one workgroup per op, which moves all pieces of its message in order -- every wait is for the workgroup of the
+// MATCHING op in the peer's launch, all workgroups of a launch are resident (at most 2 (P - 1) of them), and the waits
+// are bounded as in peer_xchg_kernel (the receive buffer is then filled with NaN).
+struct PeerOp { Real* buf; unsigned long long count, first_msg; int peer, send; };
+constexpr int kPeerMaxOps = 62;  // per round; ranks up to 32 (the kernel argument block is 4 KB)
+struct PeerOps { PeerOp op[kPeerMaxOps]; };
+__device__ inline bool peer_wait_ge (const unsigned long long* p, const unsigned long long v, const unsigned long long max_polls) {
+  unsigned long long polls = 0;
+  while (__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < v) {
+    if (++polls > max_polls) return false;
+    __builtin_amdgcn_s_sleep(8);
+  }
+  return true;
+}
+__global__ void peer_p2p_kernel (const PeerTable t, const PeerOps ops, const int me, const int nranks, const size_t cap,
+                                 const size_t p2p_off /* bytes from a mailbox's start to its point-to-point region */,
+                                 const unsigned long long max_polls) {
+  const PeerOp o = ops.op[blockIdx.x];
+  const size_t P = static_cast<size_t>(nranks);
+  // region: flag[2][P], ack[2][P] (u64), then slots[2][P][cap]
+  auto flag = [&] (unsigned char* mb, const int par, const int src) {
+    return reinterpret_cast<unsigned long long*>(mb + p2p_off) + par*P + src; };
+  auto ack = [&] (unsigned char* mb, const int par, const int dst) {
+    return reinterpret_cast<unsigned long long*>(mb + p2p_off) + 2*P + par*P + dst; };
+  auto slot = [&] (unsigned char* mb, const int par, const int src) {
+    return reinterpret_cast<unsigned long long*>(mb + p2p_off) + 4*P + (par*P + src)*cap; };
+  unsigned char* const mine = t.base[me];
+  unsigned char* const theirs = t.base[o.peer];
+  __shared__ int ok;
+  unsigned long long* const buf = reinterpret_cast<unsigned long long*>(o.buf);
+  unsigned long long msg = o.first_msg;
+  for (size_t off = 0; off < o.count; off += cap, ++msg) {
+    const size_t n = o.count - off < cap ? o.count - off : cap;
+    const int par = static_cast<int>(msg & 1);
+    if (o.send) {
+      // the slot is free once the peer has consumed my message msg - 2 (its ack, in MY mailbox, is then msg - 1)
+      if (threadIdx.x == 0) ok = msg < 2 || peer_wait_ge(ack(mine, par, o.peer), msg - 1, max_polls);
+      __syncthreads();
+      if ( ! ok) return;  // (the peer will give up as well)
+      unsigned long long* const dst = slot(theirs, par, me);
+      for (size_t i = threadIdx.x; i < n; i += blockDim.x)
+        __hip_atomic_store(dst + i, buf[off + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __threadfence_system();
+      __syncthreads();
+      if (threadIdx.x == 0)
+        __hip_atomic_store(flag(theirs, par, me), msg + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    } else {
+      if (threadIdx.x == 0) ok = peer_wait_ge(flag(mine, par, o.peer), msg + 1, max_polls);
+      __syncthreads();
+      __threadfence_system();
+      if ( ! ok) {
+        for (size_t i = off + threadIdx.x; i < o.count; i += blockDim.x) buf[i] = 0x7ff8000000000000ull;
+        if (threadIdx.x == 0)
+          __hip_atomic_store(reinterpret_cast<unsigned long long*>(mine) + 2, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+      }
+      const unsigned long long* const src = slot(mine, par, o.peer);
+      for (size_t i = threadIdx.x; i < n; i += blockDim.x)
+        buf[off + i] = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __syncthreads();  // every thread has read the slot before it is handed back
+      if (threadIdx.x == 0)
+        __hip_atomic_store(ack(theirs, par, me), msg + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __syncthreads();
+  }
+}
+
 // The three operations as ONE launch (the default form; CEDR_HIP_PEER_WAIT=stream: the three above): workgroup r stores this rank's block into rank r's
 // mailbox and announces it (nothing to itself: its own block is read from `send`), then waits IN THE KERNEL for the
 // P - 1 other ranks' arrivals in this rank's mailbox, then takes -- source r's block (all-gather), or the r-th share of
@@ -317,7 +389,9 @@ struct PeerMailbox {
   bool taken = false;  // a mailbox serves ONE communicator: its counters count that communicator's collectives
   PeerHandle handle;
   ~PeerMailbox () { if (mem) (void) hipFree(mem); }
-  size_t bytes () const { return kMailboxHead + 2*static_cast<size_t>(nranks)*cap*sizeof(Real); }
+  // [head: 2 counters, error word][collectives: 2 x P slots][point to point: 2 x P flags, 2 x P acks, 2 x P slots]
+  size_t p2p_off () const { return kMailboxHead + 2*static_cast<size_t>(nranks)*cap*sizeof(Real); }
+  size_t bytes () const { return p2p_off() + 4*static_cast<size_t>(nranks)*8 + 2*static_cast<size_t>(nranks)*cap*sizeof(Real); }
 };
 
 namespace {
@@ -419,6 +493,42 @@ struct PeerFlagComm : public Comm {
   }
   int allgather (const Real* send, Real* recv, size_t count, hipStream_t s) override {
     return collective(send, recv, count, 0, s);
+  }
+  // messages sent to / received from every peer so far (pieces of a long message count one each)
+  std::vector<unsigned long long> nsent_, nrecvd_;
+  bool has_exchange () const override {
+#ifdef __HIPCC__
+    return size_ <= kPeerMaxOps/2 + 1;
+#else
+    return false;
+#endif
+  }
+  int exchange (const P2P* ops, int nops, hipStream_t s) override {
+    if (nops == 0) return 0;
+#ifdef __HIPCC__
+    if ( ! has_exchange() || nops > kPeerMaxOps) return -2;
+    if (nsent_.empty()) { nsent_.assign(size_, 0); nrecvd_.assign(size_, 0); }
+    PeerOps po;
+    std::memset(&po, 0, sizeof(po));
+    const size_t cap = mine_->cap;
+    int n = 0;
+    for (int i = 0; i < nops; ++i) {
+      if (ops[i].peer < 0 || ops[i].peer >= size_ || ops[i].peer == rank_) return -2;
+      if (ops[i].count == 0) continue;  // (both sides know the count: nothing travels)
+      unsigned long long& seq = ops[i].send ? nsent_[ops[i].peer] : nrecvd_[ops[i].peer];
+      po.op[n++] = PeerOp{ops[i].buf, ops[i].count, seq, ops[i].peer, ops[i].send ? 1 : 0};
+      seq += (ops[i].count + cap - 1)/cap;
+    }
+    if (n == 0) return 0;
+    if (const int eo = ord_.before(s)) return eo;
+    hipLaunchKernelGGL(peer_p2p_kernel, dim3(n), dim3(256), 0, s, tab_, po, rank_, size_, cap, mine_->p2p_off(), max_polls_);
+    const int e = static_cast<int>(hipGetLastError());
+    const int ea = ord_.after(s);
+    return e ? e : ea;
+#else
+    (void) ops; (void) s;
+    return -3;
+#endif
   }
   int allreduce_sum (const Real* send, Real* recv, size_t count, hipStream_t s) override {
     return collective(send, recv, count, 1, s);

@@ -106,7 +106,8 @@ Parallel::Ptr make_parallel_rehearsal (const Parallel::Ptr& inner, int pretended
 // must not overlap. Slots and counters alternate between two parities by collective number, which
 // is what makes reuse safe without a second handshake (cedr_mpi.cpp). Replaces, for these two collectives, the
 // reference's per-level MPI messages (cedr_qlt.cpp:327-337,432-439) and MPI_Allreduce (cedr_caas.cpp:203-209), like
-// the RCCL backend; point-to-point rounds (exchange) are not offered, so plans that need them are refused.
+// the RCCL backend. Point-to-point rounds (exchange: partial trees, scattered ownership) run over the same mailboxes
+// with per-pair message slots, flags and acks, one launch per round, for up to 32 ranks.
 // Setup: every rank creates its mailbox, the launcher gathers the kPeerHandleBytes-byte handles of all ranks (rank
 // order) by any means it has, and make_parallel_peer_flags maps them. One node only; at most kPeerFlagsMaxRanks ranks.
 struct PeerMailbox;

@@ -6,7 +6,8 @@ tests/test_gpu_peer_flags.py: usage  peer_flags_worker.py RANK SIZE DIR.
 The mailbox handles go from rank to rank through files in DIR. Every rank then runs, over ONE communicator: QLT through
 the all-gather (36 harness tracers, twice, two different sets of values in turn), CAAS's all-reduce, the BFB reducer
 (inputs scaled by powers of two from call to call, so a stale slot or an early wake-up shows; one call at a time and
-in bursts of 16 without host synchronisation), QLT and CAAS alternating on two streams -- and compares ITS cells bit for bit with the single-rank oracle (CAAS's own
+in bursts of 16 without host synchronisation), QLT through per-level point-to-point rounds (partial trees, forced, pseudorandom
+ownership) and the reducer from a partial tree, QLT and CAAS alternating on two streams -- and compares ITS cells bit for bit with the single-rank oracle (CAAS's own
 all-reduce: 1e-13 per tracer, and the same bits on every rank). A mismatch is recorded and reported at the end: a rank
 never leaves early, since the others would then wait for its blocks. Test infrastructure."""
 import json
@@ -46,6 +47,7 @@ def main():
     rank, size, d = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
     slot = int(os.environ.get("PEER_SLOT_DOUBLES", "4096"))
     rep = int(os.environ.get("PEER_REPEAT", "1"))  # soaks: every loop below this many times longer
+    os.environ.setdefault("CEDR_HIP_PEER_GIVE_UP_LOG2", "23")  # a wait that is never answered ends after seconds (NaN)
     if os.environ.get("PEER_DEVICE_PER_RANK") == "1":  # a box with several GPUs: rank r on GPU r (never run so far)
         import torch
         torch.cuda.set_device(rank)
@@ -165,6 +167,49 @@ def main():
         for j, r_ in enumerate(rds):
             if not np.array_equal(r_.numpy(), bwant * 2.0 ** ((it + j) % 4)):
                 bad.append("BFB burst %d call %d" % (it, j))
+
+    # ---- point-to-point rounds (Comm::exchange over the mailboxes: per-pair slots, flags, acks): QLT from partial trees,
+    # from a full tree with per-level rounds forced, and with pseudorandom ownership; the BFB reducer from a partial tree
+    if size > 1:
+        for partial, exch, pseudo in ((True, None, False), (False, "2", False), (False, None, True)):
+            if exch:
+                os.environ["CEDR_HIP_EXCHANGE"] = exch
+            else:
+                os.environ.pop("CEDR_HIP_EXCHANGE", None)
+            t2 = ca.Tree.make_1d(ncells, size, pseudo, False)
+            if partial:
+                t2 = t2.prune(rank)
+            q2 = ca.QLT(par, ncells, t2, False)
+            for t in types:
+                q2.declare_tracer(t, 0)
+            q2.end_tracer_declarations()
+            q2.finish_setup()
+            if partial or exch:
+                assert q2.plan()["level_mode"]
+            g2 = q2.get_owned_glblcells()
+            od2 = ca.DeviceArray(len(types) * len(g2))
+            for it in range(2 * rep):
+                v = vs[it % 2]
+                d2 = [ca.DeviceArray.from_numpy(np.ascontiguousarray(a)) for a in
+                      (v.rhom[g2], v.Qm[:, g2], v.Qm_min[:, g2], v.Qm_max[:, g2], v.Qm_prev[:, g2])]
+                q2.set_rhom(d2[0])
+                q2.set_Qm(d2[1], d2[2], d2[3], d2[4])
+                q2.run()
+                q2.get_Qm(od2)
+                ca.synchronize()
+                if not np.array_equal(od2.numpy((len(types), len(g2))), wants[it % 2][:, g2]):
+                    bad.append("QLT rounds (partial %s, exchange %s, pseudorandom %s) pass %d" % (partial, exch, pseudo, it))
+        os.environ.pop("CEDR_HIP_EXCHANGE", None)
+        bt2 = btree.prune(rank)
+        ns2 = bt2.analyze(nleaf, rank)
+        mine2 = np.array([ns2["nodes"][i][1] for i in ns2["levels"][0]["nodes"]], dtype=np.int64)
+        sends2 = [ca.DeviceArray.from_numpy(np.ascontiguousarray((glob[mine2] * 2.0 ** i).T).ravel()) for i in range(4)]
+        b2 = ca.BfbTreeAllReducer(par, bt2, nleaf, nfield)
+        for it in range(4 * rep):
+            b2.allreduce(sends2[it % 4], rd, True)
+            ca.synchronize()
+            if not np.array_equal(rd.numpy(), bwant * 2.0 ** (it % 4)):
+                bad.append("BFB from a partial tree, call %d" % it)
 
     # ---- QLT and CAAS in turn on two streams, one communicator (the bench's default mode): the cross-stream ordering
     import torch  # (only for the two streams)

@@ -28,8 +28,8 @@ def test_cdrs_over_mpi(gpu, tmp_path, nranks):
 @pytest.mark.parametrize("nranks", [2, 4])
 def test_cdrs_over_peer_flags_set_up_through_mpi(gpu, tmp_path, nranks):
     """The same C++ caller with `--peer-flags`: MPI only gathers the 96-byte mailbox handles; QLT, CAAS
-    and the BFB reducer then run over cedr::mpi::make_parallel_peer_flags, bitwise against the single-rank run; partial
-    trees are refused at construction (the transport has no point-to-point rounds)."""
+    and the BFB reducer then run over cedr::mpi::make_parallel_peer_flags, bitwise against the single-rank run -- partial
+    trees included (per-level point-to-point rounds over the mailboxes)."""
     exe = os.path.join(ROOT, "tests", "cpp", "cedr_test_mpi")
     subprocess.check_call(["make", "-s", "-C", os.path.dirname(exe), "cedr_test_mpi"])
     res = subprocess.run([MPIEXEC, "-np", str(nranks), exe, "--peer-flags"], capture_output=True, text=True, timeout=600,
