@@ -362,8 +362,12 @@ def main():
                                                                  next(e for e in errs if e)), file=sys.stderr)
                 dist.destroy_process_group()
                 sys.exit(3)
-            transport = ("%s: one communicator of %d ranks%s, %s, collectives in program order"
-                         % (a.comm, world, " (ALL ON GPU 0: a rehearsal)" if a.same_gpu else "",
+            form = ""
+            if a.comm == "peer-flags":
+                form = (" [put launch + hipStreamWaitValue64 + take launch per collective]"
+                        if os.environ.get("CEDR_HIP_PEER_WAIT") == "stream" else " [one launch per collective]")
+            transport = ("%s: one communicator of %d ranks%s%s, %s, collectives in program order"
+                         % (a.comm, world, " (ALL ON GPU 0: a rehearsal)" if a.same_gpu else "", form,
                             "two streams (event ordered)" if a.overlap else "one stream"))
         else:
             par = par2 = host_staged()
