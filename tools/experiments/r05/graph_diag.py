@@ -27,6 +27,7 @@ def case(n, nt):
         x.set_rhom(rhom)
         x.set_Qm(Qm, lo, hi, prev)
     caas.set_Qm_source(Qm)
+    torch.cuda.synchronize()  # the set_* calls above ran on the null stream; s below does not wait for it
     s = torch.cuda.Stream(device=dev)
     qlt.set_stream(s.cuda_stream)
     caas.set_stream(s.cuda_stream)
@@ -51,6 +52,9 @@ def case(n, nt):
         rows = (r1 != p1).any(dim=1).nonzero().flatten().tolist()[:8]
         print("%8d x %3d %-4s plain==plain %s  replay==replay %s  replay==plain %s (max |diff| %.3e, %d values, tracers %s)  plain after replay==plain %s"
               % (n, nt, name, torch.equal(p1, p2), torch.equal(r1, r2), torch.equal(r1, p1), d, nd, rows, torch.equal(p3, p1)), flush=True)
+        if nd:
+            cols = (r1 != p1).any(dim=0).nonzero().flatten()
+            print("      differing cells: %d, first %s last %s" % (cols.numel(), cols[:6].tolist(), cols[-6:].tolist()), flush=True)
 
 
 if __name__ == "__main__":

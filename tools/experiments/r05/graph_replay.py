@@ -31,6 +31,7 @@ def case(n, nt, steps=300):
         x.set_rhom(rhom)
         x.set_Qm(Qm, lo, hi, prev)
     caas.set_Qm_source(Qm)
+    torch.cuda.synchronize()  # the set_* calls above ran on the null stream; s below does not wait for it
     s = torch.cuda.Stream(device=dev)
     qlt.set_stream(s.cuda_stream)
     caas.set_stream(s.cuda_stream)
