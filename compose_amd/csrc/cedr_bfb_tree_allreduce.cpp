@@ -76,7 +76,10 @@ BfbTreeAllReducerHip::~BfbTreeAllReducerHip () {}
 
 void BfbTreeAllReducerHip::get_host_buffers_sizes (size_t& buf1, size_t& buf2) { buf1 = buf2 = 0; }
 void BfbTreeAllReducerHip::set_host_buffers (Real*, Real*) {}
-void BfbTreeAllReducerHip::set_stream (hipStream_t stream) { m_->stream = stream; }
+void BfbTreeAllReducerHip::set_stream (hipStream_t stream) {
+  dev::follow_stream(m_->stream, stream);
+  m_->stream = stream;
+}
 
 void BfbTreeAllReducerHip::finish_setup () {
   if (m_->bd.size()) return;

@@ -165,7 +165,10 @@ Int CAASHip::get_num_tracers () const { return static_cast<Int>(probs_h_.size())
 
 const CAASHip::DeviceOp& CAASHip::get_device_op () { return o; }
 
-void CAASHip::set_stream (hipStream_t stream) { m_->stream = stream; }
+void CAASHip::set_stream (hipStream_t stream) {
+  dev::follow_stream(m_->stream, stream);
+  m_->stream = stream;
+}
 void CAASHip::set_Qm_source (const Real* qm_src) {
   // (the fused CAAS + BFB reducer kernel for groups of 2..32 cells uses 16-byte accesses)
   cedr_throw_if(m_->bfb && qm_src && reinterpret_cast<uintptr_t>(qm_src) % 16 != 0 &&

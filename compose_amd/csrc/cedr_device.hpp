@@ -41,6 +41,19 @@ public:
   size_t size () const { return n_; }
 };
 
+// A CDR's work moves from stream `from` to stream `to` (set_stream): whatever the object enqueued on the old stream --
+// a set_Qm's packing kernels, say -- is ordered before what it enqueues on the new one. Streams made non-blocking (every
+// torch stream is) do not wait for the null stream by themselves.
+inline void follow_stream (hipStream_t from, hipStream_t to) {
+  if (from == to) return;
+  hipEvent_t ev = nullptr;
+  cedr_hip_check(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  hipError_t e = hipEventRecord(ev, from);
+  if (e == hipSuccess) e = hipStreamWaitEvent(to, ev, 0);
+  (void) hipEventDestroy(ev);  // (released once the recorded work has completed)
+  cedr_hip_check(e);
+}
+
 }  // namespace dev
 }  // namespace cedr
 

@@ -383,7 +383,10 @@ Int QLTHip::get_num_tracers () const { return static_cast<Int>(md_.trcr2prob.siz
 
 const QLTHip::DeviceOp& QLTHip::get_device_op () { return o; }
 
-void QLTHip::set_stream (hipStream_t stream) { d_->stream = stream; }
+void QLTHip::set_stream (hipStream_t stream) {
+  dev::follow_stream(d_->stream, stream);  // e.g. set_Qm on the old stream, run() on the new one
+  d_->stream = stream;
+}
 const std::string& QLTHip::placement_report () const { return d_->placement; }
 
 hipEvent_t QLTHip::sweep_down_event () {

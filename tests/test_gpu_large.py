@@ -344,3 +344,51 @@ def test_mixed_types_class_forms_at_scale(gpu, oracle, monkeypatch):
     for got in outs:
         assert np.array_equal(got, want)
     assert R.check(trs, v, outs[0], False, verbose=False)[0] == 0
+
+
+def test_set_stream_orders_the_new_stream_after_the_old(gpu):
+    """set_Qm on one stream (here the null stream), then set_stream(a non-blocking stream) and run() at once, no host
+    synchronisation in between: the new stream waits for what the object enqueued on the old one (a size at which the
+    packing kernels are still running when run() is enqueued -- without the ordering its first result was garbage)."""
+    import sys
+    import torch
+    ca = gpu
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    n, nt = 750000, 40
+    dev = torch.device("cuda", 0)
+    rhom, Qm, lo, hi, prev = bench.gen_inputs(torch, n, nt, 77, dev)
+    par = ca.Parallel.self_()
+    q = ca.QLT(par, n, ca.Tree.make_1d(n, 1, False, False))
+    c = ca.CAAS(par, n)
+    for x in (q, c):
+        for _ in range(nt):
+            x.declare_tracer(7, 0)
+        x.end_tracer_declarations()
+        x.finish_setup()
+    torch.cuda.synchronize()
+    s = torch.cuda.Stream(device=dev)
+    for x in (q, c):
+        x.set_stream(None)
+        x.set_rhom(rhom)
+        x.set_Qm(Qm, lo, hi, prev)
+        x.set_stream(s.cuda_stream)
+        x.run()
+        first = torch.empty_like(Qm)
+        x.get_Qm(first)
+        torch.cuda.synchronize()
+        x.run()
+        again = torch.empty_like(Qm)
+        x.get_Qm(again)
+        torch.cuda.synchronize()
+        if x is q:  # (CAAS::run without set_Qm_source clips in place: its second run starts from the first one's result)
+            assert torch.equal(first, again)
+        x.set_stream(None)
+        x.set_rhom(rhom)
+        x.set_Qm(Qm, lo, hi, prev)
+        torch.cuda.synchronize()
+        x.run()
+        ref = torch.empty_like(Qm)
+        x.get_Qm(ref)
+        torch.cuda.synchronize()
+        assert torch.equal(first, ref), type(x).__name__
