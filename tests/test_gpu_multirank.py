@@ -87,6 +87,7 @@ def test_bench_one_gpu_stream_modes(gpu, extra, streams):
                      "--no-cpu-baseline"] + extra)
     assert res.returncode == 0, res.stdout[-1500:] + res.stderr[-1500:]
     assert d["n_gpus"] == 1 and d["check_ok"] is True and d["config"]["streams"] == streams
+    assert d["collective"] is None  # (the single-rank communicator's collectives are copies: not reported)
 
 
 def test_bench_stdout_is_the_json_line_and_a_stalled_two_stream_run_still_reports(gpu):
@@ -146,6 +147,7 @@ def test_bench_force_rccl_rank_0_of_8(gpu, extra, streams, bfb):
     assert abs(d["value"] - 2 * 30000 * 6 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
     assert d["kernels_sha256"] == gpu.kernels_sha256() and len(d["kernels_sha256"]) == 64
     assert 0 < d["qlt"]["frac"] < 1 and 0 < d["caas"]["frac"] < 1 and d["placement"]["tries_env"] == "4"
+    assert 0 < d["collective"]["allreduce_us"] < 1000 and 0 < d["collective"]["allgather_us"] < 1000  # one real RCCL call each
     if bfb:
         assert d["caas"]["fused_with_bfb_reducer"] is True and d["caas"]["bytes_per_cell_tracer"] == 64.0
 

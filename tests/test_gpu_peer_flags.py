@@ -76,6 +76,8 @@ def test_bench_over_peer_flags_ranks_on_one_gpu(gpu, nranks, extra, env):
     assert d["config"]["streams"] == (1 if "--serial" in extra else 2)
     assert d["config"]["transport"].startswith("peer-flags: one communicator of %d ranks (ALL ON GPU 0" % nranks)
     assert d["config"]["rccl_nranks"] == 0
+    # the line also carries what one collective of this communicator costs (and that its results were right)
+    assert d["collective"]["results_ok"] is True and 0 < d["collective"]["allreduce_us"] < 5000
 
 
 @pytest.mark.parametrize("env", [{}, STREAM])
