@@ -547,38 +547,6 @@ def main():
     t_qlt = timed(qlt.run)
     t_caas = timed(caas.run)
 
-    # What ONE collective of this run's communicator costs, the way a step uses it: 160 doubles (CAAS::run's all-reduce at 40
-    # tracers), 200 calls back to back on one stream, max over ranks; results checked. Only for a real transport (RCCL or
-    # peer flags, also as the one-rank communicator of a rehearsal): after the timed steps, which the same collectives
-    # have been through already. Reported next to the step, never part of `value`.
-    coll = None
-    if (world > 1 and a.comm in ("rccl", "peer-flags")) or a.force_rccl or (world == 1 and a.comm == "peer-flags"):
-        P = par.size()
-        cnt, calls = 160, 200
-        base = torch.arange(cnt, dtype=torch.float64, device=device)
-        send = base + 1000.0 * par.rank()
-        rs = torch.empty(cnt, dtype=torch.float64, device=device)
-        rg = torch.empty(cnt * P, dtype=torch.float64, device=device)
-        coll = {"doubles": cnt, "calls_back_to_back": calls}
-        for name, fn in (("allreduce", lambda: par.allreduce_sum(send, rs, cnt)), ("allgather", lambda: par.allgather(send, rg, cnt))):
-            for _ in range(20):
-                fn()
-            torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(calls):
-                fn()
-            torch.cuda.synchronize()
-            e = time.perf_counter() - t0
-            if world > 1:
-                tt = torch.tensor([e], dtype=torch.float64)
-                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                e = float(tt[0])
-            coll[name + "_us"] = 1e6 * e / calls
-        if world > 1 or a.pretend_ranks == 1:  # (a rehearsal's other blocks are copies of this rank's: nothing to compare with)
-            want_sum = base * P + 1000.0 * sum(range(P))
-            want_blocks = torch.cat([base + 1000.0 * r for r in range(P)])
-            coll["results_ok"] = bool(torch.equal(rs, want_sum) and torch.equal(rg, want_blocks))
-
     # Roofline leg: HIP events around every kernel launch, on the launch stream,
     # over `steps` more steps of the same loop, with the two CDRs on ONE stream so
     # that a kernel's duration is not stretched by a concurrent one.
@@ -589,6 +557,41 @@ def main():
     # roofline leg below), reported next to the two-stream `value` at every N: the two programs differ only in
     # the overlap, so a regression of the cross-stream ordering over real RCCL shows up as a difference here.
     t_serial = (dt_one / a.steps) if dt_one is not None else (timed(step) if streams else dt / a.steps)
+
+    # What ONE collective of this run's communicator costs, the way a step uses it: 160 doubles (CAAS::run's all-reduce at 40
+    # tracers), 200 calls back to back on one stream, max over ranks; results checked. Only for a real transport (RCCL or
+    # peer flags, also as the one-rank communicator of a rehearsal): after the timed steps, which the same collectives
+    # have been through already, on the stream the one-stream steps have just used. Reported next to the step, never part of `value`.
+    coll = None
+    if (world > 1 and a.comm in ("rccl", "peer-flags")) or a.force_rccl or (world == 1 and a.comm == "peer-flags"):
+        try:
+            P = par.size()
+            cnt, calls = 160, 200
+            base = torch.arange(cnt, dtype=torch.float64, device=device)
+            send = base + 1000.0 * par.rank()
+            rs = torch.empty(cnt, dtype=torch.float64, device=device)
+            rg = torch.empty(cnt * P, dtype=torch.float64, device=device)
+            coll = {"doubles": cnt, "calls_back_to_back": calls}
+            for name, fn in (("allreduce", lambda: par.allreduce_sum(send, rs, cnt)), ("allgather", lambda: par.allgather(send, rg, cnt))):
+                for _ in range(20):
+                    fn()
+                torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(calls):
+                    fn()
+                torch.cuda.synchronize()
+                e = time.perf_counter() - t0
+                if world > 1:
+                    tt = torch.tensor([e], dtype=torch.float64)
+                    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                    e = float(tt[0])
+                coll[name + "_us"] = 1e6 * e / calls
+            if world > 1 or a.pretend_ranks == 1:  # (a rehearsal's other blocks are copies of this rank's: nothing to compare with)
+                want_sum = base * P + 1000.0 * sum(range(P))
+                want_blocks = torch.cat([base + 1000.0 * r for r in range(P)])
+                coll["results_ok"] = bool(torch.equal(rs, want_sum) and torch.equal(rg, want_blocks))
+        except Exception as e:  # noqa: BLE001 -- an extra: never the reason the line is lost (every rank runs the same code)
+            coll = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
     ca.profile_start()
     for _ in range(a.steps):
         step()
