@@ -47,7 +47,7 @@ def main():
     rank, size, d = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
     slot = int(os.environ.get("PEER_SLOT_DOUBLES", "4096"))
     rep = int(os.environ.get("PEER_REPEAT", "1"))  # soaks: every loop below this many times longer
-    os.environ.setdefault("CEDR_HIP_PEER_GIVE_UP_LOG2", "23")  # a wait that is never answered ends after seconds (NaN)
+    os.environ.setdefault("CEDR_HIP_PEER_GIVE_UP_LOG2", "25")  # a wait that is never answered ends within a minute (NaN)
     if os.environ.get("PEER_DEVICE_PER_RANK") == "1":  # a box with several GPUs: rank r on GPU r (never run so far)
         import torch
         torch.cuda.set_device(rank)
